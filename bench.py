@@ -1,0 +1,249 @@
+"""Benchmark of the policy-update hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one training batch of the Qwen3-0.6B
+reverse_text GRPO recipe (128 rollouts of 128 tokens, 16 rollouts per
+micro-batch: 8 packed rows of T = 2048 tokens, vocabulary V = 151936).  Per
+packed row the path takes the model's logits, already resident in HBM, to the
+loss, the logged tensors and the gradient with respect to the logits:
+
+    sample boundaries -> per-token logprob + entropy (one pass over the logits)
+    -> ratio-clip loss + dL/dlogprob -> dL/dlogits (second pass) -> statistics
+
+Every rank runs the same amount of work on its own rollouts (data parallel, no
+collective on the data path); the reported value is the job total.  Rank 0
+prints ONE JSON line.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent
+if str(REPO) not in sys.path:
+    sys.path.insert(0, str(REPO))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# Qwen3-0.6B reverse_text GRPO (configs/reverse_text/rl/orch.toml of the reference)
+VOCAB = 151936
+SEQ_LEN = 128
+MICRO_BATCH = 16
+BATCH = 128
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+
+def parse() -> argparse.Namespace:
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--logits-dtype", choices=["bf16", "f32"], default="bf16",
+                   help="storage type of the logits and of their gradient (arithmetic is fp32 either way)")
+    p.add_argument("--data", choices=["near", "fake"], default="near",
+                   help="near: old logprobs close to the new ones, advantages +-0.5 (every token has a gradient); "
+                        "fake: the reference's FakeDataLoader distribution")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of the baseline sample")
+    p.add_argument("--no-stats", action="store_true", help="leave the logged statistics out of the step")
+    return p.parse_args()
+
+
+def make_batch(dev, dtype, kind: str, seed: int):
+    """Synthetic micro-batches shaped like the reference's FakeDataLoader
+    (src/prime_rl/trainer/rl/data.py:39-54), generated on the device."""
+    import prime_rl_cse_amd as prl
+
+    g = torch.Generator(device=dev).manual_seed(seed)
+    t = MICRO_BATCH * SEQ_LEN
+    rows = []
+    for _ in range(BATCH // MICRO_BATCH):
+        logits = torch.empty(1, t, VOCAB, dtype=dtype, device=dev)
+        for r in range(0, t, 512):
+            logits[0, r : r + 512] = (torch.randn(512, VOCAB, generator=g, device=dev) * 2.5).to(dtype)
+        ids = torch.randint(0, 100, (1, t), generator=g, device=dev)
+        pos = torch.cat([torch.arange(SEQ_LEN, device=dev)] * MICRO_BATCH).unsqueeze(0)
+        mask = torch.ones(1, t, dtype=torch.bool, device=dev)
+        if kind == "fake":
+            adv = torch.randn(1, t, generator=g, device=dev)
+            old = torch.randn(1, t, generator=g, device=dev)
+        else:
+            adv = torch.where(torch.rand(1, t, generator=g, device=dev) < 0.5, -0.5, 0.5)
+            with torch.no_grad():
+                lp = prl.selective_log_softmax(prl.shift_logits(logits), ids)
+            old = lp + 0.05 * torch.randn(1, t, generator=g, device=dev)
+        rows.append({"logits": logits, "input_ids": ids, "position_ids": pos, "advantages": adv,
+                     "logprobs": old, "loss_mask": mask, "temperature": 1.0})
+    return rows
+
+
+def run_step(rows, cfg, with_stats: bool):
+    """The hot loop of src/prime_rl/trainer/rl/train.py:264-333 and :364 from the
+    logits onward."""
+    import prime_rl_cse_amd as prl
+
+    loss_scale = sum(int(r["loss_mask"].numel()) for r in rows)  # masks are all ones: no sync needed to count them
+    tensors = prl.Tensors()
+    out = None
+    for r in rows:
+        logits = r["logits"].requires_grad_(True)
+        logits.grad = None
+        loss, aux = prl.policy_loss(logits, r["input_ids"], r["position_ids"], r["advantages"], r["logprobs"],
+                                    r["loss_mask"], r["temperature"], cfg, loss_scale)
+        loss.backward()
+        out = logits.grad
+        if with_stats:
+            m = r["loss_mask"]
+            tensors.add("probs", torch.exp(aux["logprobs"]), m)
+            tensors.add("old_probs", torch.exp(r["logprobs"]), m)
+            tensors.add("entropy", aux["entropy"], m)
+            tensors.add("loss", loss.detach().reshape(1))
+            for k in ("importance_ratio", "clipped_importance_ratio", "is_clipped"):
+                tensors.add(k, aux[k], m)
+    stats = tensors.compute_stats() if with_stats else {}
+    return out, stats
+
+
+def cpu_baseline(rows, seconds: float) -> dict:
+    """The CPU oracle (a restatement of the reference's torch code, which runs
+    the same torch CPU kernels) on a bounded sample of the same workload."""
+    from oracle import ref_cpu as O
+
+    threads = torch.get_num_threads()
+    host = [{k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in rows[i % len(rows)].items()}
+            for i in range(2)]
+    scale = sum(int(r["loss_mask"].numel()) for r in rows)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        r = host[done % len(host)]
+        O.policy_epilogue(r["logits"], r["input_ids"], r["position_ids"], r["advantages"], r["logprobs"],
+                          r["loss_mask"], r["temperature"], O.LossConfig(), scale)
+        done += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or done >= 8:
+            break
+    return {
+        "value": done * MICRO_BATCH / el,
+        "unit": "samples/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{done} packed rows of T={MICRO_BATCH * SEQ_LEN}, V={VOCAB} (logits -> loss, entropy, dlogits) "
+                  f"in {el:.1f} s with torch CPU kernels on {threads} threads",
+    }
+
+
+def main() -> None:
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with torch.distributed.run, one rank per GPU")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import prime_rl_cse_amd as prl
+    from prime_rl_cse_amd import _capi
+
+    dtype = torch.bfloat16 if args.logits_dtype == "bf16" else torch.float32
+    es = 2 if dtype == torch.bfloat16 else 4
+    cfg = prl.LossConfig()
+    rows = make_batch(dev, dtype, args.data, 1234 + rank)
+    with_stats = not args.no_stats
+
+    for _ in range(args.warmup):
+        run_step(rows, cfg, with_stats)
+
+    timer = _capi.KernelTimer()
+    _capi.set_timer(timer)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run_step(rows, cfg, with_stats)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    _capi.set_timer(None)
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * BATCH / (elapsed / args.steps)
+
+    if rank == 0:
+        t = MICRO_BATCH * SEQ_LEN
+        k = timer.summary()
+        bwd, fwd = k["prl_logprob_bwd"], k["prl_logprob_entropy_fwd"]
+        # algorithmic bytes per launch: the backward reads V logits for every row that
+        # carries a gradient (all but the one dropped by the shift) and writes V
+        # gradient elements for every row; the forward reads V logits for T-1 rows
+        bwd_bytes = (t - 1) * VOCAB * es + t * VOCAB * es
+        fwd_bytes = (t - 1) * VOCAB * es + 12 * t
+        achieved = bwd_bytes / (bwd["mean_ms"] * 1e-3) / 1e9
+        line = {
+            "metric": "policy_update_samples_per_sec",
+            "value": value,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "Qwen3-0.6B reverse_text GRPO policy update from resident logits: per step 8 packed rows "
+                            f"of T={t} tokens x V={VOCAB} {args.logits_dtype} logits -> sample boundaries, logprob, "
+                            "entropy, ratio-clip loss, dlogits" + (", logged statistics" if with_stats else ""),
+                "global_batch": world * BATCH,
+                "seq_len": SEQ_LEN,
+                "micro_batch": MICRO_BATCH,
+                "logits_storage": args.logits_dtype,
+                "inputs": args.data,
+                "parallelism": f"dp{world}",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_logprob_bwd",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "bytes_per_launch": bwd_bytes,
+                "mean_ms": bwd["mean_ms"],
+                "launches": bwd["launches"],
+            },
+            "kernels": {
+                "k_logprob_fwd": {"mean_ms": fwd["mean_ms"], "GBps": fwd_bytes / (fwd["mean_ms"] * 1e-3) / 1e9},
+                "k_logprob_bwd": {"mean_ms": bwd["mean_ms"], "GBps": achieved},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(rows, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,166 @@
+/*
+ * prl_hip.h: C ABI of libprl_hip.so, the MI355X (gfx950) implementation of
+ * the policy-update hot path of an RL post-training trainer.
+ *
+ * The reference this library stands in for is pure Python on top of torch; it
+ * has no FFI of its own for this path.  Each entry point below therefore names
+ * the reference CALLABLE it replaces (file:line relative to the reference
+ * root), and the Python package next to this header keeps those callables'
+ * names and signatures on top of these functions.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the comment says "host";
+ *   - every buffer is allocated and owned by the caller; the library allocates
+ *     nothing and keeps no state between calls except a thread-local error text;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *     kernels are enqueued on it and the call returns without synchronising;
+ *   - return value: PRL_OK (0) or a negative PRL_E* code, with a description
+ *     available from prl_last_error() on the calling thread;
+ *   - logits are row-major [T, V] with `row_stride` ELEMENTS between rows,
+ *     dtype PRL_F32 or PRL_BF16; all arithmetic is fp32;
+ *   - a packed row holds several samples back to back; token t belongs to
+ *     sample seg_id[t], sample s covers [seg_start[s], seg_start[s+1]).
+ */
+#ifndef PRL_HIP_H
+#define PRL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PRL_OK 0
+#define PRL_EINVAL (-1)   /* bad argument (null pointer, negative size, ...) */
+#define PRL_ELAUNCH (-2)  /* the HIP runtime refused a launch or a query    */
+#define PRL_EDTYPE (-3)   /* unsupported dtype code                          */
+
+#define PRL_F32 0
+#define PRL_BF16 1
+
+#define PRL_RATIO_TOKEN 0
+#define PRL_RATIO_SEQUENCE 1
+
+#define PRL_ADV_DRGRPO 0
+#define PRL_ADV_DRGRPO_NEGCLIPPED 1
+#define PRL_ADV_RLOO 2
+#define PRL_ADV_OPO 3
+
+/* Text of the last error on this thread ("" if none). Never NULL. */
+const char* prl_last_error(void);
+
+/* ABI version of the library: bumped when a signature changes. */
+int prl_abi_version(void);
+
+/*
+ * Bytes of device scratch prl_logprob_entropy_fwd wants for a [T, V] problem.
+ * 0 means "none needed" (enough rows to fill the chip with one workgroup per
+ * row).  Passing less (or NULL) is allowed and only costs speed at small T.
+ */
+size_t prl_logprob_workspace_bytes(int64_t T, int64_t V);
+
+/*
+ * Per-token log-probability and entropy over the vocabulary in ONE pass over
+ * the logits.  Replaces the chain
+ *     shift_logits            src/prime_rl/trainer/rl/loss.py:51-58
+ *     / temperature           src/prime_rl/trainer/rl/train.py:287
+ *     selective_log_softmax   src/prime_rl/trainer/rl/loss.py:13-39
+ *     compute_entropy         src/prime_rl/trainer/rl/loss.py:43-47
+ * without materialising the shifted or scaled copies.
+ *
+ *   shift = 1: token t is scored with logits row t-1; token 0 with an all-zero
+ *              row (logprob = -ln V, entropy = lse = ln V); the last logits
+ *              row is never read.
+ *   shift = 0: token t is scored with row t (the logits are already shifted).
+ *
+ * Outputs (fp32 [T], any may be NULL to skip it):
+ *   logprob[t] = x[ids[t]]/temperature - lse[t]
+ *   entropy[t] = lse[t] - sum_v softmax(x/temperature)_v * x_v/temperature
+ *   lse[t]     = logsumexp(x/temperature)
+ * An id outside [0, V) yields NaN in logprob[t] (torch.gather would raise).
+ */
+int prl_logprob_entropy_fwd(const void* logits, int logits_dtype, int64_t T, int64_t V, int64_t row_stride,
+                            const int64_t* ids, float temperature, int shift, float* logprob, float* entropy,
+                            float* lse, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Gradient of sum_t g[t] * logprob[t] with respect to the logits, in one pass:
+ *     dlogits[r, v] = g[t]/temperature * (1[v == ids[t]] - exp(x[r,v]/temperature - lse[t])),
+ *     t = r + shift.
+ * With shift = 1 the last row of dlogits is zero.  Rows whose g[t] is zero are
+ * written as zeros without reading the logits.  Replaces what autograd runs for
+ * loss.backward() through selective_log_softmax, the division and shift_logits
+ * (src/prime_rl/trainer/rl/train.py:310 back through :288-286).
+ *
+ *   g       fp32 [T]   dL/dlogprob (from prl_grpo_loss)
+ *   gscale  optional device scalar multiplied into every g[t] (autograd's
+ *           incoming gradient of the loss); NULL = 1
+ *   dlogits [T, V] with out_row_stride elements between rows, dtype out_dtype
+ */
+int prl_logprob_bwd(const void* logits, int logits_dtype, int64_t T, int64_t V, int64_t row_stride,
+                    const int64_t* ids, const float* lse, const float* g, const float* gscale, float temperature,
+                    int shift, void* dlogits, int out_dtype, int64_t out_row_stride, void* stream);
+
+/*
+ * Sample boundaries of a packed row from its position ids.  Replaces
+ * get_response_lengths (src/prime_rl/trainer/utils.py:36-69) bit for bit:
+ * index i >= 1 opens a new sample iff pos[i] == 0, pos[i-1] != 0, i+1 < T and
+ * pos[i+1] == 1.
+ *
+ *   seg_id    int32 [T]      sample index of every token (may be NULL)
+ *   seg_start int64 [T + 1]  start offsets, seg_start[n_seg] = T
+ *   n_seg     int32 [1]      number of samples (1 when T > 0, 0 when T == 0)
+ */
+int prl_segments_from_position_ids(const int64_t* pos, int64_t T, int32_t* seg_id, int64_t* seg_start,
+                                   int32_t* n_seg, void* stream);
+
+/*
+ * Ratio-clip policy loss over the samples of a packed row and its gradient
+ * with respect to the log-probabilities.  Replaces compute_loss
+ * (src/prime_rl/trainer/rl/loss.py:61-124) and autograd through it.
+ *
+ *   lp, old, adv  fp32 [T];  mask uint8 [T] (0/1, torch.bool layout)
+ *   seg_start     int64 [n_seg + 1] on the device;  n_seg int32 [1] on the device
+ *   max_seg       capacity of the per-sample arrays (>= the value in n_seg)
+ *   ratio_type    PRL_RATIO_TOKEN | PRL_RATIO_SEQUENCE;  length_norm 0/1
+ *   loss_scale    the normaliser; max(loss_scale, 1) is applied as in the reference
+ * Outputs
+ *   loss      fp32 [1]
+ *   ratio, clipped, is_clipped
+ *             token mode: fp32 [T], one value per token;
+ *             sequence mode: fp32 [max_seg], one value per sample
+ *   g         fp32 [T]  dloss/dlp (NULL to skip)
+ *   seg_loss  fp32 [max_seg] per-sample loss terms before the final sum (scratch, required)
+ */
+int prl_grpo_loss(const float* lp, const float* old, const float* adv, const uint8_t* mask,
+                  const int64_t* seg_start, const int32_t* n_seg, int64_t max_seg, int64_t T, int ratio_type,
+                  int length_norm, float clip_ratio, float loss_scale, float* loss, float* ratio, float* clipped,
+                  float* is_clipped, float* g, float* seg_loss, void* stream);
+
+/*
+ * Group-relative advantages: B rewards in consecutive groups of G.  Replaces
+ * compute_advantages (src/prime_rl/orchestrator/advantage.py:71-103) for the
+ * four kinds of its REGISTRY (:63-68).  `lengths` (int64 [B], completion
+ * lengths) is read by PRL_ADV_OPO only and may be NULL otherwise.
+ */
+int prl_group_advantage(const float* rewards, const int64_t* lengths, int64_t B, int64_t G, int kind,
+                        float* advantages, void* stream);
+
+/*
+ * mean, median, std (unbiased), min, max of the selected entries of x, as the
+ * trainer logs them (src/prime_rl/trainer/utils.py:247-251) but computed where
+ * the data lives.  mask may be NULL (all selected).
+ *
+ *   out5      fp32 [5] = {mean, median, std, min, max}; NaN-filled when nothing is selected
+ *   count     int64 [1] number of selected entries (may be NULL)
+ *   workspace device scratch of prl_masked_stats_workspace_bytes() bytes
+ */
+size_t prl_masked_stats_workspace_bytes(void);
+int prl_masked_stats(const float* x, const uint8_t* mask, int64_t n, float* out5, int64_t* count, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRL_HIP_H */

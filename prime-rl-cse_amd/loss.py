@@ -1,0 +1,370 @@
+"""Policy-update loss functions on HIP kernels, under the reference's names.
+
+The callables keep the signatures of src/prime_rl/trainer/rl/loss.py
+(`shift_logits` :51, `selective_log_softmax` :13, `compute_entropy` :43,
+`compute_loss` :61), so a training loop written against the reference reads the
+same.  Underneath, the vocabulary-wide work is one streaming pass over the
+logits in `prl_logprob_entropy_fwd` and one in `prl_logprob_bwd`; nothing
+shifted, scaled or soft-maxed is ever written to memory.
+
+`policy_loss` is the same computation as one call with no host synchronisation
+at all: sample boundaries, log-probabilities, entropy, loss and the gradient
+seed stay on the device.
+"""
+
+from __future__ import annotations
+
+from typing import Any, Sequence
+
+import torch
+from torch import Tensor
+
+from . import _capi as C
+
+# --------------------------------------------------------------------------- shifted logits as a view
+
+
+class ShiftedLogits:
+    """The model's logits [batch, seq, vocab] together with "read one position
+    back" and "divide by the temperature", kept as facts instead of copies.
+
+    `shift_logits(x)` returns one; dividing it by a temperature returns another.
+    `selective_log_softmax` and `compute_entropy` accept it and apply both facts
+    while streaming the original logits; results are fp32 whatever the logits'
+    dtype (for bf16 logits this equals the reference run on `logits.float()`).
+    `materialize()` builds the tensor the reference would have built.
+    """
+
+    def __init__(self, logits: Tensor, temperature: float = 1.0):
+        if logits.ndim != 3:
+            raise ValueError(f"logits must be [batch, seq, vocab], got {tuple(logits.shape)}")
+        self.logits = logits
+        self.temperature = float(temperature)
+        self._entropy: Tensor | None = None
+
+    @property
+    def shape(self):
+        return self.logits.shape
+
+    @property
+    def device(self):
+        return self.logits.device
+
+    def __truediv__(self, temperature: float) -> "ShiftedLogits":
+        return ShiftedLogits(self.logits, self.temperature * float(temperature))
+
+    def materialize(self) -> Tensor:
+        x = self.logits.float()
+        out = torch.zeros_like(x)
+        out[:, 1:, :] = x[:, :-1, :]
+        return out / self.temperature
+
+
+def shift_logits(logits: Tensor) -> ShiftedLogits:
+    """Removes final token logits and adds a zero logit for the first token
+    (src/prime_rl/trainer/rl/loss.py:51-58), without copying anything."""
+    return ShiftedLogits(logits)
+
+
+# --------------------------------------------------------------------------- kernel launches
+
+
+def _rows(logits: Tensor) -> Tensor:
+    if logits.stride(-1) != 1:
+        logits = logits.contiguous()
+    return logits
+
+
+def _launch_fwd(
+    logits: Tensor, index: Tensor, temperature: float, shift: bool, want_entropy: bool = True
+) -> tuple[Tensor, Tensor | None, Tensor]:
+    """logits [B, T, V] -> logprob, entropy, lse, each fp32 [B, T]."""
+    dev = C.require_device(logits, index)
+    lib = C.load()
+    b, t, v = logits.shape
+    if index.shape != (b, t):
+        raise ValueError(f"index must be [batch, seq] = {(b, t)}, got {tuple(index.shape)}")
+    if t > 0 and logits.stride(1) < v:
+        logits = logits.contiguous()
+    ids = index.to(torch.int64).contiguous()
+    lp = torch.empty((b, t), dtype=torch.float32, device=dev)
+    ent = torch.empty((b, t), dtype=torch.float32, device=dev) if want_entropy else None
+    lse = torch.empty((b, t), dtype=torch.float32, device=dev)
+    ws_bytes = lib.prl_logprob_workspace_bytes(t, v)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
+    code = C.dtype_code(logits)
+    st = C.stream_ptr(dev)
+    with torch.cuda.device(dev), C.timed("prl_logprob_entropy_fwd", dev):
+        for i in range(b):
+            C.check(
+                lib.prl_logprob_entropy_fwd(
+                    C.ptr(logits[i]), code, t, v, logits.stride(1), C.ptr(ids[i]), temperature, int(shift),
+                    C.ptr(lp[i]), C.ptr(ent[i]) if want_entropy else C.ptr(None), C.ptr(lse[i]),
+                    C.ptr(ws), ws_bytes, st,
+                ),
+                "prl_logprob_entropy_fwd",
+            )
+    return lp, ent, lse
+
+
+def _launch_bwd(
+    logits: Tensor, index: Tensor, lse: Tensor, g: Tensor, gscale: Tensor | None, temperature: float, shift: bool
+) -> Tensor:
+    """dlogits [B, T, V] in the dtype of the logits."""
+    dev = C.require_device(logits, index, lse, g, gscale)
+    lib = C.load()
+    b, t, v = logits.shape
+    out = torch.empty((b, t, v), dtype=logits.dtype, device=dev)
+    g = g.to(torch.float32).contiguous()
+    code = C.dtype_code(logits)
+    st = C.stream_ptr(dev)
+    with torch.cuda.device(dev), C.timed("prl_logprob_bwd", dev):
+        for i in range(b):
+            C.check(
+                lib.prl_logprob_bwd(
+                    C.ptr(logits[i]), code, t, v, logits.stride(1), C.ptr(index[i]), C.ptr(lse[i]), C.ptr(g[i]),
+                    C.ptr(gscale), temperature, int(shift), C.ptr(out[i]), code, v, st,
+                ),
+                "prl_logprob_bwd",
+            )
+    return out
+
+
+class _SelectiveLogSoftmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits: Tensor, index: Tensor, temperature: float, shift: bool):
+        logits = _rows(logits)
+        lp, ent, lse = _launch_fwd(logits, index, temperature, shift)
+        ids = index.to(torch.int64).contiguous()
+        ctx.save_for_backward(logits, ids, lse)
+        ctx.temperature, ctx.shift = temperature, shift
+        ctx.mark_non_differentiable(ent)
+        return lp, ent
+
+    @staticmethod
+    def backward(ctx, grad_lp: Tensor, _grad_ent):
+        logits, ids, lse = ctx.saved_tensors
+        return _launch_bwd(logits, ids, lse, grad_lp, None, ctx.temperature, ctx.shift), None, None, None
+
+
+def selective_log_softmax(logits: Tensor | ShiftedLogits, index: Tensor) -> Tensor:
+    """log softmax(logits)[index] per position, differentiable with respect to
+    the logits (src/prime_rl/trainer/rl/loss.py:13-39).
+
+    A `ShiftedLogits` argument is scored with its shift and temperature applied
+    on the fly, in fp32.  A plain tensor is taken as already shifted and scaled;
+    a plain bf16 tensor gives bf16 results, as the reference's low-precision
+    branch does."""
+    if isinstance(logits, ShiftedLogits):
+        lp, ent = _SelectiveLogSoftmax.apply(logits.logits, index, logits.temperature, True)
+        logits._entropy = ent
+        return lp
+    lp, _ = _SelectiveLogSoftmax.apply(logits, index, 1.0, False)
+    return lp if logits.dtype == torch.float32 else lp.to(logits.dtype)
+
+
+def compute_entropy(shifted_logits: Tensor | ShiftedLogits) -> Tensor:
+    """H = logsumexp(x) - sum softmax(x) x (src/prime_rl/trainer/rl/loss.py:43-47).
+
+    For a `ShiftedLogits` that `selective_log_softmax` has already seen, the
+    entropy was produced by that same pass and is returned as is."""
+    if isinstance(shifted_logits, ShiftedLogits):
+        if shifted_logits._entropy is not None:
+            return shifted_logits._entropy
+        x, temp, shift = shifted_logits.logits, shifted_logits.temperature, True
+    else:
+        x, temp, shift = shifted_logits, 1.0, False
+    x = _rows(x.detach())
+    dummy = torch.zeros(x.shape[:2], dtype=torch.int64, device=x.device)
+    _, ent, _ = _launch_fwd(x, dummy, temp, shift)
+    return ent
+
+
+# --------------------------------------------------------------------------- ratio-clip loss
+
+
+def _ratio_code(loss_config: Any) -> int:
+    if loss_config.ratio_type == "token":
+        return C.RATIO_TOKEN
+    if loss_config.ratio_type == "sequence":
+        return C.RATIO_SEQUENCE
+    raise ValueError(f"unknown ratio_type {loss_config.ratio_type!r}")
+
+
+def _launch_loss(
+    lp: Tensor, old: Tensor, adv: Tensor, mask: Tensor, seg_start: Tensor, n_seg: Tensor, max_seg: int,
+    loss_config: Any, loss_scale: float,
+) -> tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
+    """Flat fp32 [T] inputs -> loss [1], ratio, clipped, is_clipped, g."""
+    dev = C.require_device(lp, old, adv, mask, seg_start, n_seg)
+    lib = C.load()
+    t = lp.numel()
+    per_seq = _ratio_code(loss_config) == C.RATIO_SEQUENCE
+    n_aux = max_seg if per_seq else t
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    ratio = torch.empty(n_aux, dtype=torch.float32, device=dev)
+    clipped = torch.empty(n_aux, dtype=torch.float32, device=dev)
+    is_clipped = torch.empty(n_aux, dtype=torch.float32, device=dev)
+    g = torch.empty(t, dtype=torch.float32, device=dev)
+    seg_loss = torch.empty(max(max_seg, 1), dtype=torch.float32, device=dev)
+    mask_u8 = mask.contiguous().view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8).contiguous()
+    with torch.cuda.device(dev), C.timed("prl_grpo_loss", dev):
+        C.check(
+            lib.prl_grpo_loss(
+                C.ptr(lp), C.ptr(old), C.ptr(adv), C.ptr(mask_u8), C.ptr(seg_start), C.ptr(n_seg), max_seg, t,
+                _ratio_code(loss_config), int(bool(loss_config.ratio_length_norm)), float(loss_config.clip_ratio),
+                float(loss_scale), C.ptr(loss), C.ptr(ratio), C.ptr(clipped), C.ptr(is_clipped), C.ptr(g),
+                C.ptr(seg_loss), C.stream_ptr(dev),
+            ),
+            "prl_grpo_loss",
+        )
+    return loss, ratio, clipped, is_clipped, g
+
+
+def _flat32(x: Tensor) -> Tensor:
+    return x.reshape(-1).to(torch.float32).contiguous()
+
+
+class _GrpoLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, lp, old, adv, mask, seg_start, n_seg, max_seg, loss_config, loss_scale):
+        loss, ratio, clipped, is_clipped, g = _launch_loss(
+            lp.detach().contiguous(), old, adv, mask, seg_start, n_seg, max_seg, loss_config, loss_scale
+        )
+        ctx.save_for_backward(g)
+        ctx.mark_non_differentiable(ratio, clipped, is_clipped)
+        return loss.reshape(()), ratio, clipped, is_clipped
+
+    @staticmethod
+    def backward(ctx, grad_loss, *_):
+        (g,) = ctx.saved_tensors
+        return (g * grad_loss,) + (None,) * 8
+
+
+def compute_loss(
+    logprobs: Sequence[Tensor],
+    old_logprobs: Sequence[Tensor],
+    advantages: Sequence[Tensor],
+    loss_mask: Sequence[Tensor],
+    loss_config: Any,
+    loss_scale: float,
+) -> tuple[Tensor, dict[str, Tensor]]:
+    """Loss for packed sequences given as one tensor per sample
+    (src/prime_rl/trainer/rl/loss.py:61-124).  All samples run in one launch;
+    the returned scalar is differentiable with respect to `logprobs`."""
+    logprobs, old_logprobs = list(logprobs), list(old_logprobs)
+    advantages, loss_mask = list(advantages), list(loss_mask)
+    lengths = [int(x.numel()) for x in logprobs]
+    if not (len(old_logprobs) == len(advantages) == len(loss_mask) == len(lengths)):
+        raise ValueError("compute_loss: the four sample lists must have the same length")
+    n = len(lengths)
+    if n == 0:
+        raise ValueError("compute_loss: no samples given")
+    dev = C.require_device(*logprobs)
+    starts = [0]
+    for k in lengths:
+        starts.append(starts[-1] + k)
+    seg_start = torch.tensor(starts, dtype=torch.int64).to(dev, non_blocking=True)
+    n_seg = torch.tensor([n], dtype=torch.int32).to(dev, non_blocking=True)
+    lp = torch.cat([x.reshape(-1) for x in logprobs]).float()
+    old = _flat32(torch.cat([x.reshape(-1) for x in old_logprobs]))
+    adv = _flat32(torch.cat([x.reshape(-1) for x in advantages]))
+    mask = torch.cat([x.reshape(-1) for x in loss_mask])
+    loss, ratio, clipped, is_clipped = _GrpoLoss.apply(
+        lp, old, adv, mask, seg_start, n_seg, n, loss_config, loss_scale
+    )
+    return loss, {
+        "importance_ratio": ratio,
+        "clipped_importance_ratio": clipped,
+        "is_clipped": is_clipped,
+    }
+
+
+# --------------------------------------------------------------------------- the whole epilogue as one call
+
+
+def segments_from_position_ids(position_ids: Tensor) -> tuple[Tensor, Tensor, Tensor]:
+    """seg_id int32 [T], seg_start int64 [T + 1], n_seg int32 [1], all on the
+    device and without a host round trip (rule of src/prime_rl/trainer/utils.py:36-69)."""
+    dev = C.require_device(position_ids)
+    lib = C.load()
+    pos = position_ids.reshape(-1).to(torch.int64).contiguous()
+    t = pos.numel()
+    seg_id = torch.empty(t, dtype=torch.int32, device=dev)
+    seg_start = torch.empty(t + 1, dtype=torch.int64, device=dev)
+    n_seg = torch.empty(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev), C.timed("prl_segments_from_position_ids", dev):
+        C.check(
+            lib.prl_segments_from_position_ids(
+                C.ptr(pos), t, C.ptr(seg_id), C.ptr(seg_start), C.ptr(n_seg), C.stream_ptr(dev)
+            ),
+            "prl_segments_from_position_ids",
+        )
+    return seg_id, seg_start, n_seg
+
+
+class _PolicyLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, input_ids, position_ids, advantages, old_logprobs, loss_mask, temperature,
+                loss_config, loss_scale):
+        logits = _rows(logits)
+        t = logits.shape[1]
+        ids = input_ids.to(torch.int64).contiguous()
+        lp, ent, lse = _launch_fwd(logits, ids, temperature, True)
+        _, seg_start, n_seg = segments_from_position_ids(position_ids)
+        # a sample needs at least two tokens to open, so T // 2 + 1 bounds their number
+        max_seg = t // 2 + 1 if t > 0 else 0
+        loss, ratio, clipped, is_clipped, g = _launch_loss(
+            lp.reshape(-1), _flat32(old_logprobs), _flat32(advantages), loss_mask.reshape(-1), seg_start, n_seg,
+            max_seg, loss_config, loss_scale,
+        )
+        ctx.save_for_backward(logits, ids, lse, g)
+        ctx.temperature = temperature
+        ctx.mark_non_differentiable(lp, ent, ratio, clipped, is_clipped, seg_start, n_seg)
+        return loss.reshape(()), lp, ent, ratio, clipped, is_clipped, seg_start, n_seg
+
+    @staticmethod
+    def backward(ctx, grad_loss, *_):
+        logits, ids, lse, g = ctx.saved_tensors
+        gscale = grad_loss.to(torch.float32).reshape(1).contiguous()
+        d = _launch_bwd(logits, ids, lse, g.reshape(1, -1), gscale, ctx.temperature, True)
+        return (d,) + (None,) * 8
+
+
+def policy_loss(
+    logits: Tensor,
+    input_ids: Tensor,
+    position_ids: Tensor,
+    advantages: Tensor,
+    old_logprobs: Tensor,
+    loss_mask: Tensor,
+    temperature: float,
+    loss_config: Any,
+    loss_scale: float,
+) -> tuple[Tensor, dict[str, Tensor]]:
+    """One micro-batch of the trainer's hot loop from the model's logits to a
+    differentiable loss (src/prime_rl/trainer/rl/train.py:285-303) in one call
+    and without any host synchronisation.
+
+    logits [1, T, V] (bf16 or fp32, straight from the model); the other tensors
+    [1, T] as the `MicroBatch` holds them.  Returns the loss and a dict with
+    `logprobs`, `entropy` (fp32 [1, T]), the three ratio tensors of
+    `compute_loss`, and the device-side sample table (`seg_start`, `n_seg`).
+    In sequence mode the ratio tensors have room for T // 2 + 1 samples, of
+    which the first `n_seg` are filled.  Calling `.backward()` on the loss runs
+    one more pass over the logits and leaves dlogits in `logits.grad`."""
+    if logits.ndim != 3 or logits.shape[0] != 1:
+        raise ValueError(f"policy_loss takes one packed row, logits [1, T, V]; got {tuple(logits.shape)}")
+    loss, lp, ent, ratio, clipped, is_clipped, seg_start, n_seg = _PolicyLoss.apply(
+        logits, input_ids, position_ids, advantages, old_logprobs, loss_mask, float(temperature), loss_config,
+        float(loss_scale),
+    )
+    return loss, {
+        "logprobs": lp,
+        "entropy": ent,
+        "importance_ratio": ratio,
+        "clipped_importance_ratio": clipped,
+        "is_clipped": is_clipped,
+        "seg_start": seg_start,
+        "n_seg": n_seg,
+    }
