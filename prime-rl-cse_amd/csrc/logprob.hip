@@ -9,7 +9,43 @@
 // one multiply, so no shifted or scaled copy of the logits is ever written.
 #include "prl_common.h"
 
+// Build-time tunables (the defaults are the measured best on MI355X; the
+// tuning script under tools/ builds variants by overriding them).
+#ifndef PRL_NT_LOAD
+#define PRL_NT_LOAD 1  // non-temporal hint on the streaming loads of the logits
+#endif
+#ifndef PRL_NT_STORE
+#define PRL_NT_STORE 0  // non-temporal hint on the streaming stores of the gradient (measured: plain stores are 17 % faster)
+#endif
+#ifndef PRL_FWD_THREADS
+#define PRL_FWD_THREADS 256
+#endif
+#ifndef PRL_BWD_THREADS
+#define PRL_BWD_THREADS 256
+#endif
+#ifndef PRL_FWD_UNR
+#define PRL_FWD_UNR 4  // 16-byte loads in flight per lane in the forward
+#endif
+#ifndef PRL_BWD_LOADS
+#define PRL_BWD_LOADS 4  // 16-byte loads in flight per lane in the backward
+#endif
+
 namespace prl {
+
+__device__ __forceinline__ u32x4 stream_load(const u32x4* p) {
+#if PRL_NT_LOAD
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void stream_store(u32x4 v, u32x4* p) {
+#if PRL_NT_STORE
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
 
 // Running soft-max statistics of the values seen so far, in the base-2 domain
 // (y = x / temperature * log2 e):  m = max y,  s = sum 2^(y-m),  w = sum y 2^(y-m).
@@ -138,20 +174,23 @@ __device__ __forceinline__ void reduce_range(const char* p, int64_t n, float c, 
 
   const u32x4* vp = reinterpret_cast<const u32x4*>(p + head * ES);
   int64_t vi = tid;
-  for (; vi + 3 * NT < nvec; vi += 4 * NT) {
-    const u32x4 a0 = __builtin_nontemporal_load(vp + vi);
-    const u32x4 a1 = __builtin_nontemporal_load(vp + vi + NT);
-    const u32x4 a2 = __builtin_nontemporal_load(vp + vi + 2 * NT);
-    const u32x4 a3 = __builtin_nontemporal_load(vp + vi + 3 * NT);
-    float y[4 * VE];
-    decode16<DT>(a0, c, y);
-    decode16<DT>(a1, c, y + VE);
-    decode16<DT>(a2, c, y + 2 * VE);
-    decode16<DT>(a3, c, y + 3 * VE);
-    absorb<4 * VE>(r, y);
+  constexpr int UNR = PRL_FWD_UNR;
+  for (; vi + (UNR - 1) * NT < nvec; vi += UNR * NT) {
+    u32x4 a[UNR];
+#pragma unroll
+    for (int q = 0; q < UNR; ++q) a[q] = stream_load(vp + vi + q * NT);
+    // fold four vectors at a time: one rescale per group keeps the exp count at one per element
+#pragma unroll
+    for (int q0 = 0; q0 < UNR; q0 += 4) {
+      constexpr int GRP = UNR < 4 ? UNR : 4;
+      float y[GRP * VE];
+#pragma unroll
+      for (int q = 0; q < GRP; ++q) decode16<DT>(a[q0 + q], c, y + q * VE);
+      absorb<GRP * VE>(r, y);
+    }
   }
   for (; vi < nvec; vi += NT) {
-    const u32x4 a0 = __builtin_nontemporal_load(vp + vi);
+    const u32x4 a0 = stream_load(vp + vi);
     float y[VE];
     decode16<DT>(a0, c, y);
     absorb<VE>(r, y);
@@ -266,7 +305,7 @@ __device__ __forceinline__ void store_unit(char* outp, int64_t unit, const float
       v.y = __float_as_uint(d[4 * q + 1]);
       v.z = __float_as_uint(d[4 * q + 2]);
       v.w = __float_as_uint(d[4 * q + 3]);
-      __builtin_nontemporal_store(v, o + q);
+      stream_store(v, o + q);
     }
   } else {
     static_assert(U == 8 || DTO == PRL_F32, "bf16 output works on units of 8");
@@ -275,7 +314,7 @@ __device__ __forceinline__ void store_unit(char* outp, int64_t unit, const float
     v.y = pack_bf16(d[2], d[3]);
     v.z = pack_bf16(d[4], d[5]);
     v.w = pack_bf16(d[6], d[7]);
-    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(outp) + unit);
+    stream_store(v, reinterpret_cast<u32x4*>(outp) + unit);
   }
 }
 
@@ -284,9 +323,9 @@ __device__ __forceinline__ void load_unit(const char* inp, int64_t unit, u32x4* 
   if constexpr (DTI == PRL_F32) {
     const u32x4* p = reinterpret_cast<const u32x4*>(inp) + unit * (U / 4);
 #pragma unroll
-    for (int q = 0; q < U / 4; ++q) raw[q] = __builtin_nontemporal_load(p + q);
+    for (int q = 0; q < U / 4; ++q) raw[q] = stream_load(p + q);
   } else {
-    raw[0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(inp) + unit);
+    raw[0] = stream_load(reinterpret_cast<const u32x4*>(inp) + unit);
   }
 }
 
@@ -361,7 +400,7 @@ __global__ __launch_bounds__(NT) void k_logprob_bwd(const char* __restrict__ log
   };
 
   int64_t u = tid;
-  constexpr int UNR = (RAW == 2) ? 2 : 4;  // four 16-byte loads in flight per lane
+  constexpr int UNR = PRL_BWD_LOADS / RAW;  // units per iteration
   for (; u + (UNR - 1) * NT < nunit; u += UNR * NT) {
     u32x4 raw[UNR][RAW];
 #pragma unroll
@@ -385,8 +424,8 @@ __global__ __launch_bounds__(NT) void k_logprob_bwd(const char* __restrict__ log
 
 // ---------------------------------------------------------------- host side
 
-constexpr int kFwdThreads = 256;
-constexpr int kBwdThreads = 256;
+constexpr int kFwdThreads = PRL_FWD_THREADS;
+constexpr int kBwdThreads = PRL_BWD_THREADS;
 constexpr int64_t kFillBlocks = 2048;   // workgroups that keep 256 CUs x 8 busy
 constexpr int64_t kMinChunk = 8192;     // do not split a row into pieces smaller than this
 constexpr int kMaxSplit = 64;
