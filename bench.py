@@ -101,8 +101,8 @@ def run_step(rows, cfg, with_stats: bool):
         out = logits.grad
         if with_stats:
             m = r["loss_mask"]
-            tensors.add("probs", torch.exp(aux["logprobs"]), m)
-            tensors.add("old_probs", torch.exp(r["logprobs"]), m)
+            tensors.add("probs", aux["logprobs"], m, exp=True)
+            tensors.add("old_probs", r["logprobs"], m, exp=True)
             tensors.add("entropy", aux["entropy"], m)
             tensors.add("loss", loss.detach().reshape(1))
             for k in ("importance_ratio", "clipped_importance_ratio", "is_clipped"):

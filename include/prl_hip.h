@@ -139,6 +139,22 @@ int prl_grpo_loss(const float* lp, const float* old, const float* adv, const uin
                   float* is_clipped, float* g, float* seg_loss, void* stream);
 
 /*
+ * The forward half of one micro-batch in a single call: prl_logprob_entropy_fwd
+ * with shift = 1, prl_segments_from_position_ids and prl_grpo_loss, chained on
+ * `stream`.  Replaces the trainer's sequence src/prime_rl/trainer/rl/train.py:285-303
+ * (shift, divide, selective_log_softmax, get_response_lengths, compute_loss,
+ * compute_entropy).  The per-sample arrays (ratio, clipped, is_clipped in
+ * sequence mode, seg_loss) need room for T / 2 + 1 entries, seg_start for
+ * T + 1.  entropy, ratio, clipped, is_clipped, g and seg_id may be NULL.
+ */
+int prl_policy_forward(const void* logits, int logits_dtype, int64_t T, int64_t V, int64_t row_stride,
+                       const int64_t* ids, const int64_t* pos, const float* adv, const float* old,
+                       const uint8_t* mask, float temperature, int ratio_type, int length_norm, float clip_ratio,
+                       float loss_scale, float* logprob, float* entropy, float* lse, float* loss, float* ratio,
+                       float* clipped, float* is_clipped, float* g, float* seg_loss, int32_t* seg_id,
+                       int64_t* seg_start, int32_t* n_seg, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Group-relative advantages: B rewards in consecutive groups of G.  Replaces
  * compute_advantages (src/prime_rl/orchestrator/advantage.py:71-103) for the
  * four kinds of its REGISTRY (:63-68).  `lengths` (int64 [B], completion
@@ -148,14 +164,47 @@ int prl_group_advantage(const float* rewards, const int64_t* lengths, int64_t B,
                         float* advantages, void* stream);
 
 /*
- * mean, median, std (unbiased), min, max of the selected entries of x, as the
- * trainer logs them (src/prime_rl/trainer/utils.py:247-251) but computed where
- * the data lives.  mask may be NULL (all selected).
+ * Statistics of logged vectors: mean, median, std (unbiased), min, max, as the
+ * trainer logs them per key (src/prime_rl/trainer/utils.py:235-256: cat, gather,
+ * mean / median / std / min / max), computed where the data lives.
  *
- *   out5      fp32 [5] = {mean, median, std, min, max}; NaN-filled when nothing is selected
- *   count     int64 [1] number of selected entries (may be NULL)
- *   workspace device scratch of prl_masked_stats_workspace_bytes() bytes
+ * A statistic ("key") is the union of any number of device pieces, typically
+ * one per micro-batch.  A piece may carry a 0/1 selection mask and may ask for
+ * exp() of its values (probabilities from log-probabilities,
+ * src/prime_rl/trainer/rl/train.py:313-314).  The median is the lower middle
+ * value, as torch.median returns it, found by an exact radix select over four
+ * passes.  Call order:
+ *     prl_stats_begin; prl_stats_pass level 0, 1, 2, 3; prl_stats_finish
+ * Between passes a data-parallel job may all-reduce the scratch across ranks to
+ * obtain the statistics of all ranks' values without gathering them: after
+ * level 0 sum the regions cnt, mom and the level-0 histogram and take the
+ * maximum of ext; after levels 1..3 sum that level's histogram (region offsets
+ * from prl_stats_layout; the histogram of level L is the L-th quarter of `hist`).
  */
+#define PRL_STAT_IDENTITY 0
+#define PRL_STAT_EXP 1
+
+typedef struct prl_stat_piece {
+  const float* x;      /* device, fp32 [n] */
+  const uint8_t* mask; /* device, 0/1 per entry, or NULL = all selected */
+  int64_t n;
+  int32_t key;         /* which statistic the piece belongs to: 0 <= key < n_keys */
+  int32_t op;          /* PRL_STAT_IDENTITY or PRL_STAT_EXP */
+} prl_stat_piece;
+
+size_t prl_stats_workspace_bytes(int n_keys);
+/* offsets5 (host): byte offsets of the regions cnt (int64 [K][2]), mom (double [K][2]),
+ * ext (int32 [K][2]), hist (int32 [4][K][256]) and the total size */
+int prl_stats_layout(int n_keys, int64_t* offsets5);
+int prl_stats_begin(void* workspace, int n_keys, void* stream);
+/* pieces: HOST array of n_pieces descriptors (copied into the launch) */
+int prl_stats_pass(int level, const prl_stat_piece* pieces, int n_pieces, int n_keys, void* workspace, void* stream);
+/* out: fp32 [n_keys][5] = {mean, median, std, min, max}, NaN-filled for a key with nothing selected or with
+ * a NaN among the selected; counts: int64 [n_keys] selected entries (may be NULL) */
+int prl_stats_finish(void* workspace, int n_keys, float* out, int64_t* counts, void* stream);
+
+/* One vector, one call: the five statistics of the selected entries of x
+ * (src/prime_rl/trainer/utils.py:247-251). */
 size_t prl_masked_stats_workspace_bytes(void);
 int prl_masked_stats(const float* x, const uint8_t* mask, int64_t n, float* out5, int64_t* count, void* workspace,
                      size_t workspace_bytes, void* stream);

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 from pathlib import Path
 
 import torch
@@ -17,6 +17,15 @@ import torch
 PRL_F32, PRL_BF16 = 0, 1
 RATIO_TOKEN, RATIO_SEQUENCE = 0, 1
 ADVANTAGE_KIND = {"drgrpo": 0, "drgrpo-negclipped": 1, "rloo": 2, "opo": 3}
+
+STAT_IDENTITY, STAT_EXP = 0, 1
+
+
+class StatPiece(Structure):
+    """prl_stat_piece of include/prl_hip.h."""
+
+    _fields_ = [("x", c_void_p), ("mask", c_void_p), ("n", c_int64), ("key", c_int32), ("op", c_int32)]
+
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libprl_hip.so"
 
@@ -41,7 +50,18 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_float,
          c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     ),
+    "prl_policy_forward": (
+        c_int,
+        [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+         c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p],
+    ),
     "prl_group_advantage": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
+    "prl_stats_workspace_bytes": (c_size_t, [c_int]),
+    "prl_stats_layout": (c_int, [c_int, POINTER(c_int64)]),
+    "prl_stats_begin": (c_int, [c_void_p, c_int, c_void_p]),
+    "prl_stats_pass": (c_int, [c_int, POINTER(StatPiece), c_int, c_int, c_void_p, c_void_p]),
+    "prl_stats_finish": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "prl_masked_stats_workspace_bytes": (c_size_t, []),
     "prl_masked_stats": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
 }

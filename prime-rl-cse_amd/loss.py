@@ -303,31 +303,66 @@ def segments_from_position_ids(position_ids: Tensor) -> tuple[Tensor, Tensor, Te
     return seg_id, seg_start, n_seg
 
 
+def _u8(mask: Tensor) -> Tensor:
+    m = mask.reshape(-1)
+    return m.contiguous().view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8).contiguous()
+
+
 class _PolicyLoss(torch.autograd.Function):
+    """Forward: ONE library call (prl_policy_forward) writing into two arenas.
+    Backward: one call (prl_logprob_bwd), scaled on the device by the incoming
+    gradient of the loss."""
+
     @staticmethod
     def forward(ctx, logits, input_ids, position_ids, advantages, old_logprobs, loss_mask, temperature,
                 loss_config, loss_scale):
+        dev = C.require_device(logits, input_ids, position_ids, advantages, old_logprobs, loss_mask)
+        lib = C.load()
         logits = _rows(logits)
-        t = logits.shape[1]
-        ids = input_ids.to(torch.int64).contiguous()
-        lp, ent, lse = _launch_fwd(logits, ids, temperature, True)
-        _, seg_start, n_seg = segments_from_position_ids(position_ids)
-        # a sample needs at least two tokens to open, so T // 2 + 1 bounds their number
-        max_seg = t // 2 + 1 if t > 0 else 0
-        loss, ratio, clipped, is_clipped, g = _launch_loss(
-            lp.reshape(-1), _flat32(old_logprobs), _flat32(advantages), loss_mask.reshape(-1), seg_start, n_seg,
-            max_seg, loss_config, loss_scale,
-        )
-        ctx.save_for_backward(logits, ids, lse, g)
+        _, t, v = logits.shape
+        if t > 0 and logits.stride(1) < v:
+            logits = logits.contiguous()
+        ids = input_ids.reshape(-1).to(torch.int64).contiguous()
+        pos = position_ids.reshape(-1).to(torch.int64).contiguous()
+        adv, old, mask = _flat32(advantages), _flat32(old_logprobs), _u8(loss_mask)
+        if not (ids.numel() == pos.numel() == adv.numel() == old.numel() == mask.numel() == t):
+            raise ValueError("policy_loss: every per-token tensor must hold T entries")
+        per_seq = _ratio_code(loss_config) == C.RATIO_SEQUENCE
+        # fp32 arena: logprob, entropy, lse, g, ratio, clipped, is_clipped, seg_loss (T each) and the loss;
+        # int64 arena: seg_start (T + 1) and n_seg (int32 in the last slot)
+        f = torch.empty(8 * t + 1, dtype=torch.float32, device=dev)
+        iarena = torch.empty(t + 2, dtype=torch.int64, device=dev)
+        fp, ip = f.data_ptr(), iarena.data_ptr()
+        at = lambda k: C.c_void_p(fp + 4 * t * k)
+        ws_bytes = lib.prl_logprob_workspace_bytes(t, v)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
+        with torch.cuda.device(dev), C.timed("prl_policy_forward", dev):
+            C.check(
+                lib.prl_policy_forward(
+                    C.ptr(logits), C.dtype_code(logits), t, v, logits.stride(1), C.ptr(ids), C.ptr(pos), C.ptr(adv),
+                    C.ptr(old), C.ptr(mask), temperature, _ratio_code(loss_config),
+                    int(bool(loss_config.ratio_length_norm)), float(loss_config.clip_ratio), float(loss_scale),
+                    at(0), at(1), at(2), at(8), at(4), at(5), at(6), at(3), at(7), None, C.c_void_p(ip),
+                    C.c_void_p(ip + 8 * (t + 1)), C.ptr(ws), ws_bytes, C.stream_ptr(dev),
+                ),
+                "prl_policy_forward",
+            )
+        parts = f[: 8 * t].view(8, t)
+        lp, ent, lse, g = parts[0].view(1, t), parts[1].view(1, t), parts[2].view(1, t), parts[3].view(1, t)
+        n_aux = (t // 2 + 1 if t > 0 else 0) if per_seq else t
+        ratio, clipped, is_clipped = parts[4][:n_aux], parts[5][:n_aux], parts[6][:n_aux]
+        seg_start = iarena[: t + 1]
+        n_seg = iarena[t + 1 :].view(torch.int32)[:1]
+        ctx.save_for_backward(logits, ids.view(1, t), lse, g)
         ctx.temperature = temperature
         ctx.mark_non_differentiable(lp, ent, ratio, clipped, is_clipped, seg_start, n_seg)
-        return loss.reshape(()), lp, ent, ratio, clipped, is_clipped, seg_start, n_seg
+        return f[8 * t].reshape(()), lp, ent, ratio, clipped, is_clipped, seg_start, n_seg
 
     @staticmethod
     def backward(ctx, grad_loss, *_):
         logits, ids, lse, g = ctx.saved_tensors
         gscale = grad_loss.to(torch.float32).reshape(1).contiguous()
-        d = _launch_bwd(logits, ids, lse, g.reshape(1, -1), gscale, ctx.temperature, True)
+        d = _launch_bwd(logits, ids, lse, g, gscale, ctx.temperature, True)
         return (d,) + (None,) * 8
 
 

@@ -10,7 +10,7 @@ import torch.distributed as dist
 from torch import Tensor
 
 from . import _capi as C
-from .loss import segments_from_position_ids
+from .loss import _u8, segments_from_position_ids
 
 STAT_NAMES = ("mean", "median", "std", "min", "max")
 
@@ -38,10 +38,9 @@ def masked_stats(x: Tensor, mask: Tensor | None = None) -> tuple[Tensor, Tensor]
     xf = x.detach().reshape(-1).to(torch.float32).contiguous()
     m8 = None
     if mask is not None:
-        m = mask.reshape(-1)
-        if m.numel() != xf.numel():
+        if mask.numel() != xf.numel():
             raise ValueError("masked_stats: mask and x differ in size")
-        m8 = m.contiguous().view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8).contiguous()
+        m8 = _u8(mask)
     out = torch.empty(5, dtype=torch.float32, device=dev)
     count = torch.empty(1, dtype=torch.int64, device=dev)
     ws_bytes = lib.prl_masked_stats_workspace_bytes()
@@ -60,7 +59,9 @@ def masked_stats(x: Tensor, mask: Tensor | None = None) -> tuple[Tensor, Tensor]
 def flexible_all_gather(tensor: Tensor) -> Tensor:
     """All-gather a 1-D device tensor whose length differs per rank
     (src/prime_rl/trainer/utils.py:195-225): the sizes travel first, then one
-    padded gather; the result is the concatenation in rank order."""
+    padded gather; the result is the concatenation in rank order.  Kept for
+    callers that want the values themselves; the statistics below do not
+    gather."""
     assert tensor.ndim == 1, "Can only flexibly all-gather 1D tensors"
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return tensor
@@ -76,50 +77,85 @@ def flexible_all_gather(tensor: Tensor) -> Tensor:
     return torch.cat([gathered[r * width : r * width + n] for r, n in enumerate(sizes)])
 
 
+def _all_reduce(t: Tensor, op) -> None:
+    """In-place all-reduce of a device tensor.  RCCL ("nccl") reduces it where it
+    is; any other backend (gloo in tests) gets a synchronous host copy, because
+    gloo collectives on device tensors are not reliable when ranks share a GPU."""
+    if dist.get_backend() == "nccl":
+        dist.all_reduce(t, op=op)
+        return
+    host = t.cpu()
+    dist.all_reduce(host, op=op)
+    t.copy_(host)
+
+
 class Tensors(defaultdict):
     """Accumulates per-micro-batch vectors ON THE DEVICE and reduces each key to
-    mean / median / std / min / max over all micro-batches and ranks
+    mean / median / std / min / max over all micro-batches and all ranks
     (src/prime_rl/trainer/utils.py:228-256).
 
-    Unlike the reference nothing is copied to the host while the step runs:
-    `compute_stats` makes one device-to-host copy of 5 floats per key at the end."""
+    Nothing is copied to the host while the step runs and nothing is gathered:
+    every key is a list of device pieces, all keys are reduced together by four
+    histogram passes, and with several ranks the small scratch (about 4 KiB per
+    key) is all-reduced between the passes, which yields the exact statistics of
+    the union of all ranks' values.  `compute_stats` ends with one
+    device-to-host copy of 5 floats per key.
+
+    `tensors[key].append(x)` works as in the reference; `add` additionally takes
+    a selection mask and an `exp` flag so that neither `x[mask]` (a host
+    synchronisation) nor `torch.exp(x)` (an extra pass) has to be formed."""
 
     def __init__(self):
         super().__init__(list)
-        self._masks: dict[str, list[Tensor | None]] = defaultdict(list)
+        self._extra: dict[int, tuple[Tensor | None, int]] = {}
 
-    def add(self, key: str, values: Tensor, mask: Tensor | None = None) -> None:
-        """Record `values[mask]` for `key` without forming it: the selection is
-        applied inside the statistics kernel, so no host synchronisation (which a
-        boolean index needs to size its result) happens while the step runs."""
-        self[key].append(values.detach())
-        self._masks[key].append(mask)
+    def add(self, key: str, values: Tensor, mask: Tensor | None = None, exp: bool = False) -> None:
+        v = values.detach()
+        self[key].append(v)
+        self._extra[id(v)] = (mask, C.STAT_EXP if exp else C.STAT_IDENTITY)
 
     def compute_stats(self) -> dict[str, float]:
         keys = list(self.keys())
-        outs = []
-        multi = dist.is_initialized() and dist.get_world_size() > 1
-        for key in keys:
-            parts = self.pop(key)
-            masks = self._masks.pop(key, [])
-            masks = masks + [None] * (len(parts) - len(masks))  # entries appended the reference's way carry no mask
-            vec = torch.cat([t.reshape(-1).float() for t in parts], dim=0)
-            sel = None
-            if any(m is not None for m in masks):
-                sel = torch.cat(
-                    [
-                        (torch.ones(t.numel(), dtype=torch.bool, device=t.device) if m is None else m.reshape(-1).bool())
-                        for t, m in zip(parts, masks)
-                    ]
-                )
-            if multi:
-                vec = flexible_all_gather(vec if sel is None else vec[sel])
-                sel = None
-            out, _ = masked_stats(vec, sel)
-            outs.append(out)
-        if not outs:
+        if not keys:
             return {}
-        host = torch.stack(outs).cpu()
+        lib = C.load()
+        keep: list[Tensor] = []  # the pieces' storage must outlive the launches
+        pieces = []
+        dev = None
+        for k, key in enumerate(keys):
+            for part in self.pop(key):
+                mask, op = self._extra.pop(id(part), (None, C.STAT_IDENTITY))
+                dev = C.require_device(part, mask)
+                x = part.reshape(-1).to(torch.float32).contiguous()
+                m8 = None if mask is None else _u8(mask)
+                if m8 is not None and m8.numel() != x.numel():
+                    raise ValueError(f"Tensors: mask and values of {key!r} differ in size")
+                keep += [x, m8]
+                pieces.append(C.StatPiece(x.data_ptr(), 0 if m8 is None else m8.data_ptr(), x.numel(), k, op))
+        self._extra.clear()
+        n_keys, n_pieces = len(keys), len(pieces)
+        table = (C.StatPiece * max(n_pieces, 1))(*pieces)
+        off = (C.c_int64 * 5)()
+        C.check(lib.prl_stats_layout(n_keys, off), "prl_stats_layout")
+        ws = torch.empty(off[4] // 8, dtype=torch.int64, device=dev)
+        out = torch.empty((n_keys, 5), dtype=torch.float32, device=dev)
+        multi = dist.is_initialized() and dist.get_world_size() > 1
+        st = C.stream_ptr(dev)
+        with torch.cuda.device(dev), C.timed("prl_stats", dev):
+            C.check(lib.prl_stats_begin(C.ptr(ws), n_keys, st), "prl_stats_begin")
+            for level in range(4):
+                C.check(lib.prl_stats_pass(level, table, n_pieces, n_keys, C.ptr(ws), st), "prl_stats_pass")
+                if multi:
+                    i32 = ws.view(torch.int32)
+                    h0 = off[3] // 4 + level * n_keys * 256
+                    _all_reduce(i32[h0 : h0 + n_keys * 256], dist.ReduceOp.SUM)
+                    if level == 0:
+                        _all_reduce(ws[off[0] // 8 : off[0] // 8 + 2 * n_keys], dist.ReduceOp.SUM)
+                        _all_reduce(ws.view(torch.float64)[off[1] // 8 : off[1] // 8 + 2 * n_keys], dist.ReduceOp.SUM)
+                        _all_reduce(i32[off[2] // 4 : off[2] // 4 + 2 * n_keys], dist.ReduceOp.MAX)
+            C.check(lib.prl_stats_finish(C.ptr(ws), n_keys, C.ptr(out), None, st), "prl_stats_finish")
+        host = out.cpu()  # the one synchronisation of the step's statistics
+        del keep
         metrics: dict[str, float] = {}
         for key, row in zip(keys, host.tolist()):
             for name, val in zip(STAT_NAMES, row):

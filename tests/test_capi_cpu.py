@@ -44,9 +44,9 @@ def test_library_exports_every_declared_symbol():
 def test_every_entry_point_cites_the_reference():
     # each compute entry point names the reference callable it replaces (file:line)
     for name in ("prl_logprob_entropy_fwd", "prl_logprob_bwd", "prl_segments_from_position_ids", "prl_grpo_loss",
-                 "prl_group_advantage", "prl_masked_stats"):
+                 "prl_policy_forward", "prl_group_advantage", "prl_stats_workspace_bytes", "prl_masked_stats_workspace_bytes"):
         before = HEADER[: HEADER.index(f" {name}(")]
-        comment = before[before.rindex("/*") :]
+        comment = before[before.rindex("\n/*") :]  # the block comment in front of the declaration
         assert re.search(r"src/prime_rl/[\w/]+\.py:\d+", comment), name
 
 
@@ -68,6 +68,15 @@ def test_bad_arguments_are_rejected_with_a_message():
     assert lib.prl_segments_from_position_ids(one, -1, one, one, one, null) == -1
     assert lib.prl_grpo_loss(one, one, one, one, one, one, 4, 8, 5, 0, 8.0, 1.0, one, one, one, one, one, one, null) == -1
     assert lib.prl_masked_stats(one, null, 5, one, null, null, 0, null) == -1
+    assert lib.prl_stats_begin(null, 3, null) == -1
+    assert lib.prl_stats_begin(one, 0, null) == -1
+    bad = (C.StatPiece * 1)(C.StatPiece(16, 0, 10, 5, 0))
+    assert lib.prl_stats_pass(0, bad, 1, 2, one, null) == -1 and b"key 5" in lib.prl_last_error()
+    assert lib.prl_stats_pass(4, bad, 0, 2, one, null) == -1
+    off = (ctypes.c_int64 * 5)()
+    assert lib.prl_stats_layout(3, off) == 0 and off[4] == lib.prl_stats_workspace_bytes(3) and off[4] % 8 == 0
+    assert lib.prl_policy_forward(one, 0, 4, 8, 8, one, one, one, one, one, 1.0, 0, 0, 8.0, 1.0, null, one, one, one,
+                                  one, one, one, one, one, null, one, one, null, 0, null) == -1
     # size queries need no device
     assert lib.prl_logprob_workspace_bytes(2048, 151936) == 0
     assert lib.prl_logprob_workspace_bytes(16, 151936) > 0

@@ -381,3 +381,87 @@ def test_masked_stats_special_values():
     assert out[1].item() == torch.median(x).item()
     out, _ = prl.masked_stats(torch.tensor([1.0, float("nan"), 3.0], device=DEV))
     assert bool(out.isnan().all())
+
+
+def test_tensors_many_keys_many_pieces():
+    """Several statistics, each the union of masked pieces, in one set of launches,
+    against torch on the concatenated selections."""
+    gen = torch.Generator().manual_seed(99)
+    tensors = prl.Tensors()
+    want = {}
+    for k, key in enumerate(["probs", "entropy", "ratio", "loss"]):
+        sel_all = []
+        for piece in range(5):
+            n = int(torch.randint(1, 3000, (1,), generator=gen))
+            x = torch.randn(n, generator=gen) - (2.0 if key == "probs" else 0.0)
+            m = torch.rand(n, generator=gen) < 0.6 if key != "loss" else None
+            if key == "probs":
+                tensors.add(key, x.to(DEV), m.to(DEV), exp=True)
+                sel_all.append(torch.exp(x)[m])
+            elif key == "loss":
+                tensors[key].append(x.to(DEV))  # the reference's way of recording
+                sel_all.append(x)
+            else:
+                tensors.add(key, x.to(DEV), m.to(DEV))
+                sel_all.append(x[m])
+        want[key] = O.tensor_stats(torch.cat(sel_all))
+    got = tensors.compute_stats()
+    assert not tensors  # drained
+    for key, w in want.items():
+        if key == "probs":  # exp() on the device differs from the host's in the last bit
+            for name in ("median", "min", "max"):
+                assert abs(got[f"{key}/{name}"] - w[name]) <= 1e-6 * abs(w[name])
+        else:
+            for name in ("median", "min", "max"):
+                assert got[f"{key}/{name}"] == w[name], (key, name)
+        assert abs(got[f"{key}/mean"] - w["mean"]) <= 1e-5 * max(1.0, abs(w["mean"]))
+        assert abs(got[f"{key}/std"] - w["std"]) <= 1e-4 * w["std"]
+
+
+def _stats_rank(rank, world, port, q):
+    import os
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        gen = torch.Generator().manual_seed(500 + rank)
+        tensors = prl.Tensors()
+        mine = {}
+        for key in ("a", "b"):
+            n = 700 + 300 * rank
+            x = torch.randn(n, generator=gen) * (1 + rank)
+            m = torch.rand(n, generator=gen) < 0.5
+            tensors.add(key, x.to(DEV), m.to(DEV))
+            mine[key] = x[m]
+        got = tensors.compute_stats()
+        q.put((rank, got, {k: v.tolist() for k, v in mine.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tensors_across_ranks_without_gathering():
+    """Two ranks (gloo, sharing the one GPU): all-reducing the scratch between the
+    passes gives the statistics of the union of both ranks' values, bit-exact for
+    median / min / max."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29731
+    procs = [ctx.Process(target=_stats_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    union = {k: torch.tensor(sum((r[2][k] for r in sorted(results)), [])) for k in ("a", "b")}
+    for _, got, _ in results:
+        for k, vals in union.items():
+            w = O.tensor_stats(vals)
+            for name in ("median", "min", "max"):
+                assert got[f"{k}/{name}"] == w[name]
+            assert abs(got[f"{k}/mean"] - w["mean"]) <= 1e-5
+            assert abs(got[f"{k}/std"] - w["std"]) <= 1e-4 * w["std"]
