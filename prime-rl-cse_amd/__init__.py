@@ -6,7 +6,9 @@ loader module of that name at the repository root.
 """
 
 from .advantage import compute_advantages, group_advantage  # noqa: F401
+from .batch import Rollout, prepare_batch, prepare_sample, to_device  # noqa: F401
 from .config import FakeDataLoaderConfig, LossConfig  # noqa: F401
+from .data import DataLoader, FakeDataLoader, MicroBatch, save_rollout_batches  # noqa: F401
 from .loss import (  # noqa: F401
     ShiftedLogits,
     compute_entropy,
@@ -16,4 +18,5 @@ from .loss import (  # noqa: F401
     selective_log_softmax,
     shift_logits,
 )
+from .world import get_world, reset_world  # noqa: F401
 from .utils import Tensors, flexible_all_gather, get_response_lengths, masked_stats  # noqa: F401

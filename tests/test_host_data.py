@@ -1,0 +1,154 @@
+"""Host side of the path: packing rollouts into micro-batches (against the
+reference's vectors), the rollout file format and the loaders, and the
+world_size-2 sharding over gloo."""
+
+import os
+from pathlib import Path
+
+import pytest
+import torch
+
+import prime_rl_cse_amd as prl
+from prime_rl_cse_amd import batch as B
+from prime_rl_cse_amd import data as D
+from prime_rl_cse_amd.world import get_world, reset_world
+from tests.helpers import load_npz
+
+KEYS = ("input_ids", "advantages", "loss_mask", "position_ids", "logprobs")
+
+
+def rollouts_of_case(d, case):
+    n_roll, mbs, seq_len = d[f"c{case}__meta"].tolist()
+    out = []
+    for j in range(n_roll):
+        p = d[f"c{case}__r{j}__prompt"].tolist()
+        out.append(
+            B.Rollout(j, p, [0] * len(p), d[f"c{case}__r{j}__completion"].tolist(), d[f"c{case}__r{j}__cmask"].tolist(),
+                      d[f"c{case}__r{j}__clogp"].tolist(), False, 0.0, float(d[f"c{case}__r{j}__adv"]))
+        )
+    return out, n_roll, mbs, seq_len
+
+
+@pytest.mark.parametrize("case", range(4))
+@pytest.mark.parametrize("w", (1, 2, 4))
+def test_prepare_batch_matches_reference_vectors(case, w):
+    d = load_npz("batches.npz")
+    rollouts, n_roll, mbs, seq_len = rollouts_of_case(d, case)
+    got = prl.prepare_batch(rollouts, 0.7, None, n_roll, mbs, seq_len, w)
+    assert len(got) == w
+    for rank in range(w):
+        assert len(got[rank]) == int(d[f"c{case}__w{w}__rank{rank}__rows"])
+        for m, row in enumerate(got[rank]):
+            assert row["temperature"] == 0.7
+            for k in KEYS:
+                want = d[f"c{case}__w{w}__rank{rank}__mb{m}__{k}"]
+                assert row[k].dtype == want.dtype and torch.equal(row[k], want), (rank, m, k)
+
+
+def test_too_long_rollout_is_refused():
+    r = B.Rollout(0, [1] * 5, [0] * 5, [2] * 5, [1] * 5, [-0.1] * 5, False, 0.0, 0.0)
+    with pytest.raises(ValueError, match="greater than sequence length"):
+        prl.prepare_sample(r, 9)
+
+
+@pytest.fixture
+def clean_world(monkeypatch):
+    reset_world()
+    yield monkeypatch
+    reset_world()
+
+
+def test_world_reads_torchrun_env(clean_world):
+    for k, v in dict(RANK="3", WORLD_SIZE="8", LOCAL_RANK="3", LOCAL_WORLD_SIZE="8").items():
+        clean_world.setenv(k, v)
+    w = get_world()
+    assert (w.rank, w.world_size, w.local_rank, w.num_nodes, w.is_master) == (3, 8, 3, 1, False)
+    assert get_world() is w
+
+
+def test_fake_loader_shapes_and_sharding(clean_world):
+    # src/prime_rl/trainer/rl/data.py:30: micro-batches per rank = batch // micro_batch // world
+    clean_world.setenv("WORLD_SIZE", "2")
+    clean_world.setenv("LOCAL_WORLD_SIZE", "2")
+    clean_world.setenv("RANK", "1")
+    clean_world.setenv("LOCAL_RANK", "1")
+    loader = prl.FakeDataLoader(prl.FakeDataLoaderConfig(batch_size=128, micro_batch_size=16, seq_len=128))
+    rows = loader.get_batch()
+    assert len(rows) == 4
+    r = rows[0]
+    assert r["input_ids"].shape == (1, 2048) and r["input_ids"].dtype == torch.int64
+    assert r["position_ids"][0, :130].tolist() == list(range(128)) + [0, 1]
+    assert r["loss_mask"].dtype == torch.bool and bool(r["loss_mask"].all()) and r["temperature"] == 1.0
+    assert int(r["input_ids"].max()) < 100
+    with pytest.raises(ValueError):
+        prl.FakeDataLoaderConfig(batch_size=10, micro_batch_size=4)
+
+
+def test_rollout_files_round_trip(tmp_path, clean_world):
+    d = load_npz("batches.npz")
+    rollouts, n_roll, mbs, seq_len = rollouts_of_case(d, 0)
+    per_rank = prl.prepare_batch(rollouts, 1.0, None, n_roll, mbs, seq_len, 2)
+    paths = prl.save_rollout_batches(per_rank, tmp_path, step=3)
+    assert [p.name for p in paths] == ["rank_0.pt", "rank_1.pt"] and not list(tmp_path.rglob("*.tmp"))
+    clean_world.setenv("WORLD_SIZE", "2")
+    clean_world.setenv("LOCAL_WORLD_SIZE", "2")
+    clean_world.setenv("RANK", "1")
+    clean_world.setenv("LOCAL_RANK", "1")
+    loader = prl.DataLoader(tmp_path, start_step=3)
+    assert loader.get_rollout_path() == tmp_path / "rollouts" / "step_3" / "rank_1.pt"
+    loader.wait_for_batch(interval=0.01, timeout=1)
+    got = loader.get_batch()
+    assert loader.current_step == 4 and len(got) == len(per_rank[1])
+    for a, b in zip(got, per_rank[1]):
+        assert a["temperature"] == b["temperature"]
+        for k in KEYS:
+            assert torch.equal(a[k], b[k])
+    with pytest.raises(TimeoutError):
+        loader.wait_for_batch(interval=0.01, timeout=0.05)
+
+
+def _rank_main(rank, world, port, root, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        reset_world()
+        loader = prl.DataLoader(Path(root), start_step=0)
+        loader.wait_for_batch(interval=0.01, timeout=30)
+        rows = loader.get_batch()
+        n = torch.tensor([len(rows)])
+        counts = [torch.zeros(1, dtype=torch.long) for _ in range(world)]
+        dist.all_gather(counts, n)
+        # the loss normaliser is local to the rank (src/prime_rl/trainer/rl/train.py:263-267): no collective
+        scale = sum(int(r["loss_mask"].sum()) for r in rows)
+        toks = torch.tensor([sum(r["input_ids"].numel() for r in rows)])
+        dist.all_reduce(toks)
+        q.put((rank, [int(c) for c in counts], scale, int(toks), [r["input_ids"][0].tolist() for r in rows]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_each_load_their_own_shard_over_gloo(tmp_path):
+    import torch.multiprocessing as mp
+
+    d = load_npz("batches.npz")
+    rollouts, n_roll, mbs, seq_len = rollouts_of_case(d, 1)
+    per_rank = prl.prepare_batch(rollouts, 1.0, None, n_roll, mbs, seq_len, 2)
+    prl.save_rollout_batches(per_rank, tmp_path, step=0)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, 29741, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, c0, s0, t0, ids0), (r1, c1, s1, t1, ids1) = res
+    assert c0 == c1 and c0[0] == c0[1] == len(per_rank[0])  # same number of rows on every rank
+    assert t0 == t1 == sum(r["input_ids"].numel() for rows in per_rank for r in rows)
+    assert ids0 == [r["input_ids"][0].tolist() for r in per_rank[0]]
+    assert ids1 == [r["input_ids"][0].tolist() for r in per_rank[1]]
+    assert s0 == sum(int(r["loss_mask"].sum()) for r in per_rank[0])
