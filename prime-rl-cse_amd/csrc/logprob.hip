@@ -27,7 +27,10 @@
 #define PRL_FWD_UNR 4  // 16-byte loads in flight per lane in the forward
 #endif
 #ifndef PRL_BWD_LOADS
-#define PRL_BWD_LOADS 4  // 16-byte loads in flight per lane in the backward
+#define PRL_BWD_LOADS 4  // 16-byte loads per lane and iteration in the backward
+#endif
+#ifndef PRL_BWD_PIPE
+#define PRL_BWD_PIPE 1  // 1: software-pipelined backward (next iteration's loads issued before this one's math)
 #endif
 
 namespace prl {
@@ -399,15 +402,49 @@ __global__ __launch_bounds__(NT) void k_logprob_bwd(const char* __restrict__ log
     store_unit<DTO, U>(outp, u, d);
   };
 
-  int64_t u = tid;
   constexpr int UNR = PRL_BWD_LOADS / RAW;  // units per iteration
-  for (; u + (UNR - 1) * NT < nunit; u += UNR * NT) {
+  constexpr int64_t STEP = (int64_t)UNR * NT;
+  int64_t u = tid;
+#if PRL_BWD_PIPE
+  // Two register sets in ping-pong: the loads of the next iteration are in
+  // flight while this iteration's exponentials and stores run.
+  u32x4 ra[UNR][RAW], rb[UNR][RAW];
+  bool have_a = u + (UNR - 1) * NT < nunit;
+  if (have_a) {
+#pragma unroll
+    for (int q = 0; q < UNR; ++q) load_unit<DTI, U>(inp, u + q * NT, ra[q]);
+  }
+  while (have_a) {
+    const bool have_b = u + STEP + (UNR - 1) * NT < nunit;
+    if (have_b) {
+#pragma unroll
+      for (int q = 0; q < UNR; ++q) load_unit<DTI, U>(inp, u + STEP + q * NT, rb[q]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < UNR; ++q) finish_unit(u + q * NT, ra[q]);
+    u += STEP;
+    if (!have_b) break;
+    have_a = u + STEP + (UNR - 1) * NT < nunit;
+    if (have_a) {
+#pragma unroll
+      for (int q = 0; q < UNR; ++q) load_unit<DTI, U>(inp, u + STEP + q * NT, ra[q]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < UNR; ++q) finish_unit(u + q * NT, rb[q]);
+    u += STEP;
+  }
+#else
+  for (; u + (UNR - 1) * NT < nunit; u += STEP) {
     u32x4 raw[UNR][RAW];
 #pragma unroll
     for (int q = 0; q < UNR; ++q) load_unit<DTI, U>(inp, u + q * NT, raw[q]);
+    __builtin_amdgcn_sched_barrier(0);  // all loads issue before the first result is touched
 #pragma unroll
     for (int q = 0; q < UNR; ++q) finish_unit(u + q * NT, raw[q]);
   }
+#endif
   for (; u < nunit; u += NT) {
     u32x4 raw[RAW];
     load_unit<DTI, U>(inp, u, raw);

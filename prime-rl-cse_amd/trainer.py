@@ -1,0 +1,182 @@
+"""The RL trainer's step on MI355X: PyTorch-ROCm runs the transformer body,
+FSDP2 shards it over RCCL, and everything after the LM head is the HIP path of
+this package (counterpart of src/prime_rl/trainer/rl/train.py:259-364 and of the
+model set-up in src/prime_rl/trainer/model.py:55-135, :251-254).
+
+What differs from the reference loop, on purpose:
+  * the model's bf16 logits go straight into `policy_loss` (no fp32 copy, no
+    shifted copy, no divided copy, no softmax tensor);
+  * sample boundaries, loss and statistics never leave the device inside the
+    loop: the only host synchronisations of a step are the gradient-norm read
+    and the final 5-floats-per-key statistics copy;
+  * statistics over ranks are all-reduced histograms, not gathered vectors.
+"""
+
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+from typing import Any
+
+import torch
+import torch.distributed as dist
+from torch import Tensor, nn
+
+from .batch import to_device
+from .config import LossConfig
+from .data import MicroBatch
+from .loss import policy_loss
+from .utils import Tensors
+
+# Literal architecture dimensions (there is no hub access where this runs).  The
+# Qwen3-0.6B row is confirmed by the reference's own FLOP known-answer test
+# (tests/unit/train/test_perf.py:10); the others are the public model cards'.
+MODEL_DIMS: dict[str, dict[str, Any]] = {
+    "Qwen/Qwen3-0.6B": dict(family="qwen3", vocab_size=151936, hidden_size=1024, intermediate_size=3072,
+                            num_hidden_layers=28, num_attention_heads=16, num_key_value_heads=8, head_dim=128,
+                            tie_word_embeddings=True, rope_theta=1e6, rms_norm_eps=1e-6, max_position_embeddings=40960),
+    "Qwen/Qwen3-1.7B": dict(family="qwen3", vocab_size=151936, hidden_size=2048, intermediate_size=6144,
+                            num_hidden_layers=28, num_attention_heads=16, num_key_value_heads=8, head_dim=128,
+                            tie_word_embeddings=True, rope_theta=1e6, rms_norm_eps=1e-6, max_position_embeddings=40960),
+    "Qwen/Qwen2.5-0.5B": dict(family="qwen2", vocab_size=151936, hidden_size=896, intermediate_size=4864,
+                              num_hidden_layers=24, num_attention_heads=14, num_key_value_heads=2,
+                              tie_word_embeddings=True, rope_theta=1e6, rms_norm_eps=1e-6,
+                              max_position_embeddings=32768),
+    "Qwen/Qwen2.5-7B": dict(family="qwen2", vocab_size=152064, hidden_size=3584, intermediate_size=18944,
+                            num_hidden_layers=28, num_attention_heads=28, num_key_value_heads=4,
+                            tie_word_embeddings=False, rope_theta=1e6, rms_norm_eps=1e-6,
+                            max_position_embeddings=131072),
+}
+
+
+def model_config(name: str, attn: str = "sdpa", num_layers: int | None = None, **overrides: Any):
+    """A transformers config from literal dimensions; `num_layers` trims the depth
+    (the reference's `model.debug.num_layers`, src/prime_rl/trainer/model.py:64-68)."""
+    from transformers import Qwen2Config, Qwen3Config
+
+    dims = dict(MODEL_DIMS[name])
+    dims.update(overrides)
+    family = dims.pop("family")
+    if num_layers is not None:
+        dims["num_hidden_layers"] = min(num_layers, dims["num_hidden_layers"])
+    cfg = (Qwen3Config if family == "qwen3" else Qwen2Config)(**dims)
+    cfg._attn_implementation = attn
+    cfg.use_cache = False
+    return cfg
+
+
+def get_model(cfg: Any, device: torch.device | str, dtype: torch.dtype = torch.float32, seed: int = 0) -> nn.Module:
+    """A randomly initialised causal LM in `dtype` on `device` (the counterpart of
+    the reference's `random_init` debug path, src/prime_rl/trainer/model.py:144-146)."""
+    from transformers import AutoModelForCausalLM
+
+    torch.manual_seed(seed)
+    with torch.device(device):
+        model = AutoModelForCausalLM.from_config(cfg, dtype=dtype)
+    return model
+
+
+def setup_fsdp(model: nn.Module, mesh: Any, reduce_dtype: torch.dtype = torch.float32,
+               reshard_after_forward: bool = True) -> nn.Module:
+    """FSDP2 over a 1-D data-parallel mesh, grouped as the reference groups it
+    (src/prime_rl/trainer/model.py:102-135): one group per transformer block,
+    bf16 parameters on the wire, fp32 gradient reduction; for untied models the
+    embedding and [lm_head, final norm] get groups of their own."""
+    from torch.distributed.fsdp import MixedPrecisionPolicy, fully_shard
+
+    mp = MixedPrecisionPolicy(param_dtype=torch.bfloat16, reduce_dtype=reduce_dtype)
+    for block in model.model.layers:
+        fully_shard(block, mesh=mesh, mp_policy=mp, reshard_after_forward=reshard_after_forward)
+    if not model.config.tie_word_embeddings:
+        fully_shard(model.model.embed_tokens, mesh=mesh, mp_policy=mp, reshard_after_forward=reshard_after_forward)
+        fully_shard([model.lm_head, model.model.norm], mesh=mesh, mp_policy=mp, reshard_after_forward=False)
+    fully_shard(model, mesh=mesh, mp_policy=mp, reshard_after_forward=reshard_after_forward)
+    return model
+
+
+def forward(model: nn.Module, input_ids: Tensor, position_ids: Tensor) -> Tensor:
+    """Logits [batch, seq, vocab] of a packed row (src/prime_rl/trainer/model.py:251-254)."""
+    return model(input_ids=input_ids, position_ids=position_ids).logits
+
+
+@dataclass
+class StepResult:
+    loss: float
+    grad_norm: float
+    stats: dict[str, float]
+    seconds: float
+    tokens: int
+    samples: int
+    timings: dict[str, float] = field(default_factory=dict)
+
+
+def local_loss_scale(micro_batches: list[MicroBatch], loss_config: LossConfig) -> int:
+    """The normaliser of src/prime_rl/trainer/rl/train.py:263-267: unmasked tokens of
+    THIS rank's micro-batches in token mode, rows x row batch size in sequence
+    mode.  The masks are still on the host here, so counting them costs no
+    device synchronisation."""
+    if loss_config.ratio_type == "token":
+        return int(sum(int(mb["loss_mask"].sum()) for mb in micro_batches))
+    return int(micro_batches[0]["input_ids"].shape[0] * len(micro_batches))
+
+
+def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, micro_batches: list[MicroBatch],
+               loss_config: LossConfig, max_norm: float = 1.0, device: torch.device | str = "cuda",
+               scheduler: Any = None, samples: int | None = None) -> StepResult:
+    """One optimizer step over this rank's micro-batches
+    (src/prime_rl/trainer/rl/train.py:259-364)."""
+    t0 = time.perf_counter()
+    loss_scale = local_loss_scale(micro_batches, loss_config)
+    tensors = Tensors()
+    tokens = 0
+    for step_idx, host_mb in enumerate(micro_batches):
+        if hasattr(model, "set_requires_all_reduce"):
+            model.set_requires_all_reduce(step_idx == len(micro_batches) - 1)
+        mb = to_device(host_mb, device)
+        logits = forward(model, mb["input_ids"], mb["position_ids"])
+        loss, aux = policy_loss(logits, mb["input_ids"], mb["position_ids"], mb["advantages"], mb["logprobs"],
+                                mb["loss_mask"], mb["temperature"], loss_config, loss_scale)
+        del logits
+        loss.backward()
+        mask = mb["loss_mask"]
+        tensors.add("probs", aux["logprobs"], mask, exp=True)
+        tensors.add("old_probs", mb["logprobs"], mask, exp=True)
+        tensors.add("entropy", aux["entropy"], mask)
+        tensors.add("loss", loss.detach().reshape(1))
+        if loss_config.ratio_type == "token":
+            for key in ("importance_ratio", "clipped_importance_ratio", "is_clipped"):
+                tensors.add(key, aux[key], mask)
+        tokens += int(mb["input_ids"].numel())
+    grad_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=max_norm)
+    if hasattr(grad_norm, "full_tensor"):
+        grad_norm = grad_norm.full_tensor()
+    optimizer.step()
+    optimizer.zero_grad(set_to_none=True)
+    if scheduler is not None:
+        scheduler.step()
+    stats = tensors.compute_stats()
+    seconds = time.perf_counter() - t0
+    if samples is None:
+        # a packed row carries as many rollouts as it has position resets; for the
+        # synthetic loader that is the micro-batch size
+        samples = len(micro_batches)
+    return StepResult(loss=stats.get("loss/mean", float("nan")), grad_norm=float(grad_norm), stats=stats,
+                      seconds=seconds, tokens=tokens, samples=samples)
+
+
+def setup_optimizer(model: nn.Module, lr: float = 1e-6, weight_decay: float = 0.01,
+                    betas: tuple[float, float] = (0.9, 0.999)) -> torch.optim.Optimizer:
+    """AdamW with the reference's defaults (src/prime_rl/trainer/optim.py:19-25,
+    src/prime_rl/trainer/config.py:299-315)."""
+    return torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=weight_decay, betas=betas)
+
+
+def init_distributed(device: torch.device) -> Any:
+    """RCCL process group (backend "nccl" on ROCm) and the 1-D data-parallel mesh
+    (src/prime_rl/trainer/utils.py:27-33; dp_shard = world size as in
+    src/prime_rl/trainer/parallel_dims.py:251-258 with every other degree at 1)."""
+    from torch.distributed.device_mesh import init_device_mesh
+
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", device_id=device)
+    return init_device_mesh("cuda", (dist.get_world_size(),), mesh_dim_names=("dp_shard",))

@@ -24,8 +24,9 @@ LIB = REPO / "prime-rl-cse_amd" / "lib"
 TUNE = LIB / "tune"
 
 VARIANTS: dict[str, dict[str, int]] = {"base": {}}
-for th, ld in itertools.product((256, 512, 1024), (2, 4, 8)):
-    VARIANTS[f"t{th}_l{ld}"] = {"PRL_FWD_THREADS": th, "PRL_BWD_THREADS": th, "PRL_FWD_UNR": ld, "PRL_BWD_LOADS": ld}
+for pipe, th, ld in itertools.product((0, 1), (256, 512, 1024), (2, 4, 8)):
+    VARIANTS[f"p{pipe}_t{th}_l{ld}"] = {"PRL_BWD_PIPE": pipe, "PRL_FWD_THREADS": th, "PRL_BWD_THREADS": th,
+                                        "PRL_FWD_UNR": ld, "PRL_BWD_LOADS": ld}
 VARIANTS["nts1"] = {"PRL_NT_STORE": 1}
 VARIANTS["ntl0"] = {"PRL_NT_LOAD": 0}
 
