@@ -107,7 +107,9 @@ def run_step(rows, cfg, with_stats: bool):
             tensors.add("loss", loss.detach().reshape(1))
             for k in ("importance_ratio", "clipped_importance_ratio", "is_clipped"):
                 tensors.add(k, aux[k], m)
-    stats = tensors.compute_stats() if with_stats else {}
+    # the statistics are reduced on the device inside the step; their 5 floats per key reach the host
+    # asynchronously and are read one step later, as a trainer that logs step N during step N + 1 would
+    stats = tensors.compute_stats_async() if with_stats else None
     return out, stats
 
 
@@ -163,20 +165,37 @@ def main() -> None:
     with_stats = not args.no_stats
 
     for _ in range(args.warmup):
-        run_step(rows, cfg, with_stats)
+        _, pending = run_step(rows, cfg, with_stats)
+        if pending is not None:
+            pending.result()
 
-    timer = _capi.KernelTimer()
+    # inside the timed region only the dominant kernel carries events (every event pair costs a few
+    # microseconds of queue time); the other kernels are timed in a short untimed pass afterwards
+    timer = _capi.KernelTimer(only={"prl_logprob_bwd"})
     _capi.set_timer(timer)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    pending, last_stats = None, {}
     for _ in range(args.steps):
-        run_step(rows, cfg, with_stats)
+        _, fut = run_step(rows, cfg, with_stats)
+        if pending is not None:
+            last_stats = pending.result()  # step N-1's numbers, while step N runs
+        pending = fut
+    if pending is not None:
+        last_stats = pending.result()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    side = _capi.KernelTimer()
+    _capi.set_timer(side)
+    for _ in range(3):
+        _, fut = run_step(rows, cfg, with_stats)
+        if fut is not None:
+            fut.result()
+    torch.cuda.synchronize()
     _capi.set_timer(None)
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -188,8 +207,8 @@ def main() -> None:
 
     if rank == 0:
         t = MICRO_BATCH * SEQ_LEN
-        k = timer.summary()
-        bwd, fwd = k["prl_logprob_bwd"], k["prl_logprob_entropy_fwd"]
+        k = side.summary()
+        bwd, fwd = timer.summary()["prl_logprob_bwd"], k["prl_policy_forward"]
         # algorithmic bytes per launch: the backward reads V logits for every row that
         # carries a gradient (all but the one dropped by the shift) and writes V
         # gradient elements for every row; the forward reads V logits for T-1 rows
@@ -233,10 +252,15 @@ def main() -> None:
                 "launches": bwd["launches"],
             },
             "kernels": {
-                "k_logprob_fwd": {"mean_ms": fwd["mean_ms"], "GBps": fwd_bytes / (fwd["mean_ms"] * 1e-3) / 1e9},
+                # one library call: k_logprob_fwd, then k_segments and k_grpo_loss (microseconds each)
+                "prl_policy_forward": {"mean_ms": fwd["mean_ms"], "GBps": fwd_bytes / (fwd["mean_ms"] * 1e-3) / 1e9},
                 "k_logprob_bwd": {"mean_ms": bwd["mean_ms"], "GBps": achieved},
+                **({"prl_stats(all keys)": {"mean_ms": k["prl_stats"]["mean_ms"]}} if "prl_stats" in k else {}),
             },
         }
+        if last_stats:
+            line["last_step_stats"] = {k: last_stats[k] for k in ("loss/mean", "entropy/mean", "importance_ratio/mean")
+                                       if k in last_stats}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(rows, args.cpu_seconds)
         print(json.dumps(line), flush=True)

@@ -136,10 +136,13 @@ class KernelTimer:
     to (torch's current stream).  Meant for benchmarks: install one with
     `set_timer`, run, synchronise, read `summary()`."""
 
-    def __init__(self):
+    def __init__(self, only: set[str] | None = None):
         self.events: dict[str, list[tuple[torch.cuda.Event, torch.cuda.Event]]] = {}
+        self.only = only  # names to time; None = every named launch
 
     def span(self, name: str, device: torch.device):
+        if self.only is not None and name not in self.only:
+            return _no_span
         return _Span(self, name, device)
 
     def summary(self) -> dict[str, dict[str, float]]:

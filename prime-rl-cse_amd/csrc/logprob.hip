@@ -11,11 +11,21 @@
 
 // Build-time tunables (the defaults are the measured best on MI355X; the
 // tuning script under tools/ builds variants by overriding them).
-#ifndef PRL_NT_LOAD
-#define PRL_NT_LOAD 1  // non-temporal hint on the streaming loads of the logits
+#ifndef PRL_FWD_NT_LOAD
+#define PRL_FWD_NT_LOAD 1  // non-temporal hint on the forward's streaming loads of the logits
+#endif
+#ifndef PRL_BWD_NT_LOAD
+#define PRL_BWD_NT_LOAD 1  // the same for the backward's loads
 #endif
 #ifndef PRL_NT_STORE
-#define PRL_NT_STORE 0  // non-temporal hint on the streaming stores of the gradient (measured: plain stores are 17 % faster)
+#define PRL_NT_STORE 0  // non-temporal hint on the streaming stores of the gradient
+#endif
+#ifndef PRL_FWD_REVERSE
+#define PRL_FWD_REVERSE 0  // 1: workgroups take the rows last to first
+#endif
+#ifndef PRL_BWD_REVERSE
+#define PRL_BWD_REVERSE 0  // 1: the backward takes the rows last to first (the rows the forward read last are the
+                           // ones most likely still in the Infinity Cache)
 #endif
 #ifndef PRL_FWD_THREADS
 #define PRL_FWD_THREADS 256
@@ -29,18 +39,25 @@
 #ifndef PRL_BWD_LOADS
 #define PRL_BWD_LOADS 4  // 16-byte loads per lane and iteration in the backward
 #endif
-#ifndef PRL_BWD_PIPE
-#define PRL_BWD_PIPE 1  // 1: software-pipelined backward (next iteration's loads issued before this one's math)
+#ifndef PRL_BWD_FLAT
+#define PRL_BWD_FLAT 1  // 1: flat grid-stride backward when the layout allows it, else one workgroup per row
+#endif
+#ifndef PRL_BWD_FLAT_UPT
+#define PRL_BWD_FLAT_UPT 2  // work units per thread and piece in the flat backward
+#endif
+#ifndef PRL_BWD_FLAT_GRID
+#define PRL_BWD_FLAT_GRID 4096  // workgroups of the flat backward
 #endif
 
 namespace prl {
 
+template <bool NT>
 __device__ __forceinline__ u32x4 stream_load(const u32x4* p) {
-#if PRL_NT_LOAD
-  return __builtin_nontemporal_load(p);
-#else
-  return *p;
-#endif
+  if constexpr (NT) {
+    return __builtin_nontemporal_load(p);
+  } else {
+    return *p;
+  }
 }
 __device__ __forceinline__ void stream_store(u32x4 v, u32x4* p) {
 #if PRL_NT_STORE
@@ -181,7 +198,7 @@ __device__ __forceinline__ void reduce_range(const char* p, int64_t n, float c, 
   for (; vi + (UNR - 1) * NT < nvec; vi += UNR * NT) {
     u32x4 a[UNR];
 #pragma unroll
-    for (int q = 0; q < UNR; ++q) a[q] = stream_load(vp + vi + q * NT);
+    for (int q = 0; q < UNR; ++q) a[q] = stream_load<PRL_FWD_NT_LOAD>(vp + vi + q * NT);
     // fold four vectors at a time: one rescale per group keeps the exp count at one per element
 #pragma unroll
     for (int q0 = 0; q0 < UNR; q0 += 4) {
@@ -193,7 +210,7 @@ __device__ __forceinline__ void reduce_range(const char* p, int64_t n, float c, 
     }
   }
   for (; vi < nvec; vi += NT) {
-    const u32x4 a0 = stream_load(vp + vi);
+    const u32x4 a0 = stream_load<PRL_FWD_NT_LOAD>(vp + vi);
     float y[VE];
     decode16<DT>(a0, c, y);
     absorb<VE>(r, y);
@@ -225,7 +242,11 @@ __global__ __launch_bounds__(NT) void k_logprob_fwd(const char* __restrict__ log
                                                     float* __restrict__ lse_out) {
   constexpr int NW = NT / kWave;
   __shared__ float lds[3 * NW];
+#if PRL_FWD_REVERSE
+  const int64_t t = (int64_t)gridDim.x - 1 - blockIdx.x;
+#else
   const int64_t t = blockIdx.x;
+#endif
   if (shift && t == 0) {
     if (threadIdx.x == 0) emit_zero_row(V, t, lp, ent, lse_out);
     return;
@@ -326,9 +347,9 @@ __device__ __forceinline__ void load_unit(const char* inp, int64_t unit, u32x4* 
   if constexpr (DTI == PRL_F32) {
     const u32x4* p = reinterpret_cast<const u32x4*>(inp) + unit * (U / 4);
 #pragma unroll
-    for (int q = 0; q < U / 4; ++q) raw[q] = stream_load(p + q);
+    for (int q = 0; q < U / 4; ++q) raw[q] = stream_load<PRL_BWD_NT_LOAD>(p + q);
   } else {
-    raw[0] = stream_load(reinterpret_cast<const u32x4*>(inp) + unit);
+    raw[0] = stream_load<PRL_BWD_NT_LOAD>(reinterpret_cast<const u32x4*>(inp) + unit);
   }
 }
 
@@ -339,6 +360,75 @@ __device__ __forceinline__ void decode_unit(const u32x4* raw, float c, float* y)
     for (int q = 0; q < U / 4; ++q) decode16<PRL_F32>(raw[q], c, y + 4 * q);
   } else {
     decode16<PRL_BF16>(raw[0], c, y);
+  }
+}
+
+// The math of one work unit: d = -gi * 2^(y - lse2), plus gi at the label, then the store.
+template <int DTI, int DTO, int U>
+__device__ __forceinline__ void bwd_unit(const u32x4* raw, char* outp, int64_t unit, float c, float lse2, float gi,
+                                         int64_t label) {
+  float y[U], d[U];
+  decode_unit<DTI, U>(raw, c, y);
+#pragma unroll
+  for (int j = 0; j < U; ++j) d[j] = -gi * fast_exp2(y[j] - lse2);
+  const uint64_t off = (uint64_t)(label - unit * U);
+  if (off < (uint64_t)U) {
+#pragma unroll
+    for (int j = 0; j < U; ++j) d[j] += (off == (uint64_t)j) ? gi : 0.0f;
+  }
+  store_unit<DTO, U>(outp, unit, d);
+}
+
+// Flat decomposition: the [T, V] matrix is cut into pieces of NT * UPT work units that never
+// cross a row, and the workgroups walk the pieces with a grid stride, so that at any moment the
+// whole grid reads one contiguous window of the logits and writes one contiguous window of the
+// gradient (measured: a copy laid out this way moves 7 % more bytes per second than one
+// workgroup per row).  Needs every row 16-byte aligned and V a multiple of the unit size.
+template <int DTI, int DTO, int NT, int UPT>
+__global__ __launch_bounds__(NT) void k_logprob_bwd_flat(const char* __restrict__ logits, int64_t T, int64_t V,
+                                                         int64_t in_stride_bytes, const int64_t* __restrict__ ids,
+                                                         const float* __restrict__ lse, const float* __restrict__ g,
+                                                         const float* __restrict__ gscale, float inv_temp, int shift,
+                                                         char* __restrict__ out, int64_t out_stride_bytes,
+                                                         int64_t pieces_per_row, int64_t total_pieces) {
+  constexpr int U = (DTI == PRL_BF16 || DTO == PRL_BF16) ? 8 : 4;
+  constexpr int RAW = DTI == PRL_F32 ? U / 4 : 1;
+  const int tid = threadIdx.x;
+  const int64_t nunit = V / U;
+  const float c = inv_temp * kLog2e;
+  const float gs = (gscale ? gscale[0] : 1.0f) * inv_temp;
+  int64_t row = blockIdx.x / pieces_per_row, piece = blockIdx.x % pieces_per_row;
+  const int64_t drow = gridDim.x / pieces_per_row, dpiece = gridDim.x % pieces_per_row;
+  for (int64_t p = blockIdx.x; p < total_pieces; p += gridDim.x) {
+    const int64_t t = row + shift;
+    const float gi = t < T ? g[t] * gs : 0.0f;
+    const char* inp = logits + row * in_stride_bytes;
+    char* outp = out + row * out_stride_bytes;
+    const int64_t u0 = piece * (int64_t)(NT * UPT) + tid;
+    if (gi == 0.0f) {
+      float z[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) z[j] = 0.0f;
+#pragma unroll
+      for (int q = 0; q < UPT; ++q)
+        if (u0 + q * NT < nunit) store_unit<DTO, U>(outp, u0 + q * NT, z);
+    } else {
+      const float lse2 = lse[t] * kLog2e;
+      const int64_t label = ids[t];
+      u32x4 raw[UPT][RAW];
+#pragma unroll
+      for (int q = 0; q < UPT; ++q)
+        if (u0 + q * NT < nunit) load_unit<DTI, U>(inp, u0 + q * NT, raw[q]);
+#pragma unroll
+      for (int q = 0; q < UPT; ++q)
+        if (u0 + q * NT < nunit) bwd_unit<DTI, DTO, U>(raw[q], outp, u0 + q * NT, c, lse2, gi, label);
+    }
+    piece += dpiece;
+    row += drow;
+    if (piece >= pieces_per_row) {
+      piece -= pieces_per_row;
+      ++row;
+    }
   }
 }
 
@@ -355,7 +445,11 @@ __global__ __launch_bounds__(NT) void k_logprob_bwd(const char* __restrict__ log
   constexpr int U = (DTI == PRL_BF16 || DTO == PRL_BF16) ? 8 : 4;  // elements per work unit
   constexpr int RAW = DTI == PRL_F32 ? U / 4 : 1;                  // 16-byte loads per unit
   const int tid = threadIdx.x;
+#if PRL_BWD_REVERSE
+  const int64_t row = T - 1 - blockIdx.x / nsplit;
+#else
   const int64_t row = blockIdx.x / nsplit;
+#endif
   const int k = (int)(blockIdx.x % nsplit);
   const int64_t e0 = k * chunk;
   int64_t n = V - e0;
@@ -405,37 +499,6 @@ __global__ __launch_bounds__(NT) void k_logprob_bwd(const char* __restrict__ log
   constexpr int UNR = PRL_BWD_LOADS / RAW;  // units per iteration
   constexpr int64_t STEP = (int64_t)UNR * NT;
   int64_t u = tid;
-#if PRL_BWD_PIPE
-  // Two register sets in ping-pong: the loads of the next iteration are in
-  // flight while this iteration's exponentials and stores run.
-  u32x4 ra[UNR][RAW], rb[UNR][RAW];
-  bool have_a = u + (UNR - 1) * NT < nunit;
-  if (have_a) {
-#pragma unroll
-    for (int q = 0; q < UNR; ++q) load_unit<DTI, U>(inp, u + q * NT, ra[q]);
-  }
-  while (have_a) {
-    const bool have_b = u + STEP + (UNR - 1) * NT < nunit;
-    if (have_b) {
-#pragma unroll
-      for (int q = 0; q < UNR; ++q) load_unit<DTI, U>(inp, u + STEP + q * NT, rb[q]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < UNR; ++q) finish_unit(u + q * NT, ra[q]);
-    u += STEP;
-    if (!have_b) break;
-    have_a = u + STEP + (UNR - 1) * NT < nunit;
-    if (have_a) {
-#pragma unroll
-      for (int q = 0; q < UNR; ++q) load_unit<DTI, U>(inp, u + STEP + q * NT, ra[q]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < UNR; ++q) finish_unit(u + q * NT, rb[q]);
-    u += STEP;
-  }
-#else
   for (; u + (UNR - 1) * NT < nunit; u += STEP) {
     u32x4 raw[UNR][RAW];
 #pragma unroll
@@ -444,7 +507,6 @@ __global__ __launch_bounds__(NT) void k_logprob_bwd(const char* __restrict__ log
 #pragma unroll
     for (int q = 0; q < UNR; ++q) finish_unit(u + q * NT, raw[q]);
   }
-#endif
   for (; u < nunit; u += NT) {
     u32x4 raw[RAW];
     load_unit<DTI, U>(inp, u, raw);
@@ -575,11 +637,39 @@ extern "C" int prl_logprob_bwd(const void* logits, int logits_dtype, int64_t T, 
   PRL_REQUIRE(T * (int64_t)ns < (int64_t)1 << 31, "logprob_bwd: T too large");
   hipStream_t st = (hipStream_t)stream;
   const float inv_temp = 1.0f / temperature;
-  const int64_t chunk = chunk_for(V, ns);
-  const dim3 grid((unsigned)(T * ns)), block(kBwdThreads);
   const char* lg = (const char*)logits;
   char* out = (char*)dlogits;
   const int64_t sbi = row_stride * esi, sbo = out_row_stride * eso;
+#if PRL_BWD_FLAT
+  {
+    const int unit = (esi == 2 || eso == 2) ? 8 : 4;
+    const bool flat_ok = V % unit == 0 && ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits) |
+                                            (uintptr_t)sbi | (uintptr_t)sbo) & 15) == 0;
+    if (flat_ok) {
+      constexpr int UPT = PRL_BWD_FLAT_UPT;
+      const int64_t per_piece = (int64_t)kBwdThreads * UPT;
+      const int64_t ppr = (V / unit + per_piece - 1) / per_piece;
+      const int64_t total = T * ppr;
+      const dim3 fgrid((unsigned)(total < PRL_BWD_FLAT_GRID ? total : PRL_BWD_FLAT_GRID)), fblock(kBwdThreads);
+#define PRL_BWDF(DI, DO)                                                                                          \
+  hipLaunchKernelGGL((k_logprob_bwd_flat<DI, DO, kBwdThreads, UPT>), fgrid, fblock, 0, st, lg, T, V, sbi, ids, lse, \
+                     g, gscale, inv_temp, shift, out, sbo, ppr, total)
+      if (logits_dtype == PRL_F32 && out_dtype == PRL_F32)
+        PRL_BWDF(PRL_F32, PRL_F32);
+      else if (logits_dtype == PRL_F32)
+        PRL_BWDF(PRL_F32, PRL_BF16);
+      else if (out_dtype == PRL_F32)
+        PRL_BWDF(PRL_BF16, PRL_F32);
+      else
+        PRL_BWDF(PRL_BF16, PRL_BF16);
+#undef PRL_BWDF
+      PRL_CHECK_LAUNCH("logprob_bwd(flat)");
+      return PRL_OK;
+    }
+  }
+#endif
+  const int64_t chunk = chunk_for(V, ns);
+  const dim3 grid((unsigned)(T * ns)), block(kBwdThreads);
 #define PRL_BWD(DI, DO)                                                                                             \
   hipLaunchKernelGGL((k_logprob_bwd<DI, DO, kBwdThreads>), grid, block, 0, st, lg, T, V, sbi, ids, lse, g, gscale, \
                      inv_temp, shift, out, sbo, ns, chunk)

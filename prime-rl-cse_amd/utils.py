@@ -115,9 +115,18 @@ class Tensors(defaultdict):
         self._extra[id(v)] = (mask, C.STAT_EXP if exp else C.STAT_IDENTITY)
 
     def compute_stats(self) -> dict[str, float]:
+        """Reduce every key and return {"<key>/<stat>": float}; blocks until the
+        numbers are on the host."""
+        return self.compute_stats_async().result()
+
+    def compute_stats_async(self) -> "StatsFuture":
+        """Enqueue the reduction and the device-to-host copy of its result (into
+        pinned memory) and return at once.  `result()` on the returned object
+        waits for that copy only, so a trainer can log step N while step N + 1 is
+        already running."""
         keys = list(self.keys())
         if not keys:
-            return {}
+            return StatsFuture([], None, None)
         lib = C.load()
         keep: list[Tensor] = []  # the pieces' storage must outlive the launches
         pieces = []
@@ -154,10 +163,28 @@ class Tensors(defaultdict):
                         _all_reduce(ws.view(torch.float64)[off[1] // 8 : off[1] // 8 + 2 * n_keys], dist.ReduceOp.SUM)
                         _all_reduce(i32[off[2] // 4 : off[2] // 4 + 2 * n_keys], dist.ReduceOp.MAX)
             C.check(lib.prl_stats_finish(C.ptr(ws), n_keys, C.ptr(out), None, st), "prl_stats_finish")
-        host = out.cpu()  # the one synchronisation of the step's statistics
+            host = torch.empty((n_keys, 5), dtype=torch.float32, pin_memory=True)
+            host.copy_(out, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(dev))
+        # the launches hold raw pointers into `keep`, `ws` and `out`; torch's caching allocator only hands a
+        # freed block to later work on the same stream, so dropping the references here is safe
         del keep
+        return StatsFuture(keys, host, done)
+
+
+class StatsFuture:
+    """The pending result of `Tensors.compute_stats_async`."""
+
+    def __init__(self, keys: list[str], host: Tensor | None, done: "torch.cuda.Event | None"):
+        self._keys, self._host, self._done = keys, host, done
+
+    def result(self) -> dict[str, float]:
+        if self._host is None:
+            return {}
+        self._done.synchronize()  # the one host wait of the step's statistics
         metrics: dict[str, float] = {}
-        for key, row in zip(keys, host.tolist()):
+        for key, row in zip(self._keys, self._host.tolist()):
             for name, val in zip(STAT_NAMES, row):
                 metrics[f"{key}/{name}"] = val
         return metrics

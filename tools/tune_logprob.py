@@ -23,12 +23,14 @@ CSRC = REPO / "prime-rl-cse_amd" / "csrc"
 LIB = REPO / "prime-rl-cse_amd" / "lib"
 TUNE = LIB / "tune"
 
-VARIANTS: dict[str, dict[str, int]] = {"base": {}}
-for pipe, th, ld in itertools.product((0, 1), (256, 512, 1024), (2, 4, 8)):
-    VARIANTS[f"p{pipe}_t{th}_l{ld}"] = {"PRL_BWD_PIPE": pipe, "PRL_FWD_THREADS": th, "PRL_BWD_THREADS": th,
-                                        "PRL_FWD_UNR": ld, "PRL_BWD_LOADS": ld}
-VARIANTS["nts1"] = {"PRL_NT_STORE": 1}
-VARIANTS["ntl0"] = {"PRL_NT_LOAD": 0}
+VARIANTS: dict[str, dict[str, int]] = {"base": {}, "base_again": {}}  # two copies of one code: the noise floor
+VARIANTS["rows"] = {"PRL_BWD_FLAT": 0}
+for upt, grid in itertools.product((1, 2, 4), (1024, 2048, 4096, 8192)):
+    VARIANTS[f"flat_u{upt}_g{grid}"] = {"PRL_BWD_FLAT": 1, "PRL_BWD_FLAT_UPT": upt, "PRL_BWD_FLAT_GRID": grid}
+VARIANTS["flat_u1_g2048_t512"] = {"PRL_BWD_FLAT_UPT": 1, "PRL_BWD_FLAT_GRID": 2048, "PRL_BWD_THREADS": 512}
+VARIANTS["flat_u1_g1024_t512"] = {"PRL_BWD_FLAT_UPT": 1, "PRL_BWD_FLAT_GRID": 1024, "PRL_BWD_THREADS": 512}
+VARIANTS["flat_u1_g2048_nts1"] = {"PRL_BWD_FLAT_UPT": 1, "PRL_BWD_FLAT_GRID": 2048, "PRL_NT_STORE": 1}
+VARIANTS["flat_u1_g2048_bnt0"] = {"PRL_BWD_FLAT_UPT": 1, "PRL_BWD_FLAT_GRID": 2048, "PRL_BWD_NT_LOAD": 0}
 
 
 def build() -> None:
@@ -48,7 +50,7 @@ def build() -> None:
         print("built", tag, flush=True)
 
 
-def run(dtype_name: str, rounds: int, t: int, v: int) -> None:
+def run(dtype_name: str, rounds: int, t: int, v: int, producer: bool = True) -> None:
     import torch
 
     sys.path.insert(0, str(REPO))
@@ -62,6 +64,7 @@ def run(dtype_name: str, rounds: int, t: int, v: int) -> None:
     logits = torch.empty(t, v, dtype=dtype, device=dev)
     for r in range(0, t, 512):
         logits[r : r + 512] = (torch.randn(min(512, t - r), v, generator=g, device=dev) * 2.5).to(dtype)
+    src = logits.clone()
     ids = torch.randint(0, v, (t,), generator=g, device=dev)
     lp = torch.empty(t, device=dev)
     ent = torch.empty(t, device=dev)
@@ -93,23 +96,35 @@ def run(dtype_name: str, rounds: int, t: int, v: int) -> None:
     for tag, lib in libs.items():  # warm up, and check every variant agrees with the first
         assert fwd(lib) == 0 and bwd(lib) == 0
     torch.cuda.synchronize()
+    import random
+
+    rng = random.Random(0)
+    order = list(libs.items())
     for _ in range(rounds):
-        for tag, lib in libs.items():
-            for name, fn in (("fwd", fwd), ("bwd", bwd)):
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record()
-                fn(lib)
-                b.record()
-                b.synchronize()
-                times[tag][name].append(a.elapsed_time(b))
+        rng.shuffle(order)  # a fresh order every round, so that no variant always follows the same one
+        for tag, lib in order:
+            # the producer of the logits (the LM-head GEMM in the trainer) writes them just before the
+            # forward reads them; a device copy stands in for it so that the caches start from that state
+            if producer:
+                logits.copy_(src)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            ev[0].record()
+            fwd(lib)
+            ev[1].record()
+            bwd(lib)
+            ev[2].record()
+            ev[2].synchronize()
+            times[tag]["fwd"].append(ev[0].elapsed_time(ev[1]))
+            times[tag]["bwd"].append(ev[1].elapsed_time(ev[2]))
     fwd_bytes = (t - 1) * v * es
     bwd_bytes = (2 * t - 1) * v * es
     print(f"T={t} V={v} {dtype_name}: median (min) ms and GB/s at the median")
     for tag in libs:
         f, b = times[tag]["fwd"], times[tag]["bwd"]
         fm, bm = statistics.median(f), statistics.median(b)
-        print(f"{tag:16s} fwd {fm:.4f} ({min(f):.4f}) {fwd_bytes / fm / 1e6:7.0f} GB/s | "
-              f"bwd {bm:.4f} ({min(b):.4f}) {bwd_bytes / bm / 1e6:7.0f} GB/s", flush=True)
+        pair = statistics.median([x + y for x, y in zip(f, b)])
+        print(f"{tag:22s} fwd {fm:.4f} ({min(f):.4f}) {fwd_bytes / fm / 1e6:6.0f} GB/s | "
+              f"bwd {bm:.4f} ({min(b):.4f}) {bwd_bytes / bm / 1e6:6.0f} GB/s | pair {pair:.4f}", flush=True)
 
 
 if __name__ == "__main__":
@@ -119,5 +134,6 @@ if __name__ == "__main__":
     ap.add_argument("--rounds", type=int, default=20)
     ap.add_argument("--t", type=int, default=2048)
     ap.add_argument("--v", type=int, default=151936)
+    ap.add_argument("--no-producer", action="store_true", help="do not rewrite the logits before each forward")
     a = ap.parse_args()
-    build() if a.mode == "build" else run(a.dtype, a.rounds, a.t, a.v)
+    build() if a.mode == "build" else run(a.dtype, a.rounds, a.t, a.v, not a.no_producer)
