@@ -53,6 +53,12 @@ def parse() -> argparse.Namespace:
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of the baseline sample")
     p.add_argument("--no-stats", action="store_true", help="leave the logged statistics out of the step")
+    p.add_argument("--workload", choices=["epilogue", "trainer"], default="epilogue",
+                   help="epilogue: the hot path from resident logits (the headline line); trainer: the whole "
+                        "optimizer step with a random-init Qwen3-0.6B body under FSDP2")
+    p.add_argument("--no-trainer-extra", action="store_true",
+                   help="at --gpus 1, do not append the short whole-trainer-step measurement to the line")
+    p.add_argument("--trainer-steps", type=int, default=3)
     return p.parse_args()
 
 
@@ -141,6 +147,112 @@ def cpu_baseline(rows, seconds: float) -> dict:
     }
 
 
+def pmc_traffic(kernel: str, logits_dtype: str) -> tuple[float | None, str | None]:
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary whose shape matches."""
+    best = None
+    for path in sorted((REPO / "profiles").glob("*pmc_traffic.json")):
+        try:
+            d = json.loads(path.read_text())
+        except Exception:
+            continue
+        sh = d.get("shape", {})
+        if sh.get("T") == MICRO_BATCH * SEQ_LEN and sh.get("V") == VOCAB and sh.get("logits") == logits_dtype:
+            for name, vals in d.get("kernels", {}).items():
+                if name.startswith(kernel):
+                    best = (float(vals["hbm_bytes_per_launch"]), f"profiles/{path.name}")
+    return best if best else (None, None)
+
+
+def trainer_measure(dev, world: int, steps: int, warmup: int, cpu: bool, cpu_seconds: float) -> dict:
+    """The whole optimizer step of the Qwen3-0.6B reverse_text recipe on synthetic rollouts: transformer body by
+    PyTorch-ROCm (random init, bf16 compute under FSDP2, fp32 master weights and gradient reduction), everything
+    after the LM head by this package, gradient clipping and AdamW (src/prime_rl/trainer/rl/train.py:259-352)."""
+    import prime_rl_cse_amd as prl
+    from prime_rl_cse_amd import trainer as T
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    mesh = T.init_distributed(dev)
+    cfg = T.model_config("Qwen/Qwen3-0.6B")
+    model = T.get_model(cfg, dev, torch.float32, seed=0)
+    T.setup_fsdp(model, mesh)
+    opt = T.setup_optimizer(model)
+    prl.reset_world()
+    loader = prl.FakeDataLoader(prl.FakeDataLoaderConfig(batch_size=BATCH * world, micro_batch_size=MICRO_BATCH,
+                                                         seq_len=SEQ_LEN))
+    loss_cfg = prl.LossConfig()
+    batches = [loader.get_batch() for _ in range(2)]
+    for i in range(warmup):
+        T.train_step(model, opt, batches[i % 2], loss_cfg, device=dev, samples=BATCH)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        res = T.train_step(model, opt, batches[i % 2], loss_cfg, device=dev, samples=BATCH)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    sec = float(el.item()) / steps
+    flop = prl.perf.flop_per_token(cfg, SEQ_LEN) * BATCH * SEQ_LEN
+    out = {
+        "model": "Qwen3-0.6B (random init, literal dimensions)",
+        "ms_per_step": sec * 1e3,
+        "samples_per_s": world * BATCH / sec,
+        "tokens_per_s": world * BATCH * SEQ_LEN / sec,
+        "mfu_percent_of_2.5PF": 100 * flop / sec / 2.5e15,
+        "steps": steps,
+        "loss": res.loss,
+        "grad_norm": res.grad_norm,
+        "precision": "bf16 compute, fp32 master weights and gradient reduction (FSDP2 mixed precision), fp32 loss math",
+        "attention": "sdpa",
+    }
+    del model, opt
+    torch.cuda.empty_cache()
+    if cpu and world == 1:
+        out["cpu_baseline"] = trainer_cpu_baseline(batches[0], cpu_seconds)
+    return out
+
+
+def trainer_cpu_baseline(batch, seconds: float) -> dict:
+    """The same step on the host cores: fp32 model on the CPU, the oracle's loss, AdamW; a bounded sample of
+    micro-batches (the reference trainer itself refuses to run without CUDA)."""
+    from oracle import ref_cpu as O
+    from prime_rl_cse_amd import trainer as T
+
+    cfg = T.model_config("Qwen/Qwen3-0.6B")
+    model = T.get_model(cfg, "cpu", torch.float32, seed=0)
+    opt = T.setup_optimizer(model)
+    scale = sum(int(mb["loss_mask"].sum()) for mb in batch)
+    done, t0 = 0, time.perf_counter()
+    for mb in batch:
+        logits = T.forward(model, mb["input_ids"], mb["position_ids"]).float().contiguous()
+        x = O.shift_logits(logits) / mb["temperature"]
+        lp = O.selective_log_softmax(x, mb["input_ids"])
+        lens = O.get_response_lengths(mb["position_ids"])
+        loss, _ = O.compute_loss(lp.squeeze().split(lens), mb["logprobs"].squeeze().split(lens),
+                                 mb["advantages"].squeeze().split(lens), mb["loss_mask"].squeeze().split(lens),
+                                 O.LossConfig(), scale)
+        with torch.no_grad():
+            O.compute_entropy(x)
+        del logits, x
+        loss.backward()
+        done += 1
+        if time.perf_counter() - t0 >= seconds:
+            break
+    torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+    opt.step()
+    el = time.perf_counter() - t0
+    return {"value": done * MICRO_BATCH / el, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{done} micro-batches of {MICRO_BATCH} x {SEQ_LEN} tokens through an fp32 Qwen3-0.6B on the CPU "
+                      f"(forward, oracle loss, backward) plus one clip + AdamW step, {el:.1f} s"}
+
+
 def main() -> None:
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -156,7 +268,24 @@ def main() -> None:
         dist.init_process_group("nccl", device_id=dev)
 
     import prime_rl_cse_amd as prl
-    from prime_rl_cse_amd import _capi
+    from prime_rl_cse_amd import _capi, perf  # noqa: F401
+
+    if args.workload == "trainer":
+        info = trainer_measure(dev, world, args.steps, args.warmup, not args.no_cpu_baseline, args.cpu_seconds)
+        if rank == 0:
+            line = {"metric": "policy_update_samples_per_sec", "value": info["samples_per_s"], "unit": "samples/s",
+                    "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": info["ms_per_step"],
+                    "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+                    "data": "synthetic",
+                    "config": {"workload": "whole trainer step, Qwen3-0.6B reverse_text GRPO, synthetic rollouts",
+                               "global_batch": world * BATCH, "seq_len": SEQ_LEN, "micro_batch": MICRO_BATCH,
+                               "parallelism": f"fsdp{world}"},
+                    "trainer_step": info}
+            print(json.dumps(line), flush=True)
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     dtype = torch.bfloat16 if args.logits_dtype == "bf16" else torch.float32
     es = 2 if dtype == torch.bfloat16 else 4
@@ -215,6 +344,7 @@ def main() -> None:
         bwd_bytes = (t - 1) * VOCAB * es + t * VOCAB * es
         fwd_bytes = (t - 1) * VOCAB * es + 12 * t
         achieved = bwd_bytes / (bwd["mean_ms"] * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic("k_logprob_bwd", args.logits_dtype)
         line = {
             "metric": "policy_update_samples_per_sec",
             "value": value,
@@ -246,7 +376,8 @@ def main() -> None:
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "bytes_per_launch": bwd_bytes,
                 "mean_ms": bwd["mean_ms"],
                 "launches": bwd["launches"],
@@ -263,8 +394,16 @@ def main() -> None:
                                        if k in last_stats}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(rows, args.cpu_seconds)
+        if world == 1 and not args.no_trainer_extra:
+            del rows
+            torch.cuda.empty_cache()
+            try:
+                line["trainer_step"] = trainer_measure(dev, 1, args.trainer_steps, 1, not args.no_cpu_baseline,
+                                                       args.cpu_seconds)
+            except Exception as exc:  # the headline line must not depend on the transformers install
+                line["trainer_step"] = {"error": f"{type(exc).__name__}: {exc}"}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -5,6 +5,7 @@ The directory name carries a hyphen; import it as `prime_rl_cse_amd` through the
 loader module of that name at the repository root.
 """
 
+from . import perf  # noqa: F401
 from .advantage import compute_advantages, group_advantage  # noqa: F401
 from .batch import Rollout, prepare_batch, prepare_sample, to_device  # noqa: F401
 from .config import FakeDataLoaderConfig, LossConfig  # noqa: F401

@@ -67,8 +67,9 @@ __device__ __forceinline__ void stream_store(u32x4 v, u32x4* p) {
 #endif
 }
 
-// Running soft-max statistics of the values seen so far, in the base-2 domain
-// (y = x / temperature * log2 e):  m = max y,  s = sum 2^(y-m),  w = sum y 2^(y-m).
+// Running soft-max statistics of the raw logits x seen so far.  With c = log2(e) / temperature
+// (positive) and y = c * x:  m = max y,  s = sum 2^(y-m),  w = sum x 2^(y-m)  (x unscaled, so that
+// the inner loop is one fma, one exp, one add and one fma per element).
 struct Running {
   float m, s, w;
 };
@@ -77,24 +78,28 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
 
 template <int N>
-__device__ __forceinline__ void absorb(Running& r, const float (&y)[N]) {
-  float mx = y[0];
+__device__ __forceinline__ void absorb(Running& r, const float (&x)[N], float c) {
+  float mx = x[0];
 #pragma unroll
-  for (int i = 1; i < N; ++i) mx = fmaxf(mx, y[i]);
-  const float mn = fmaxf(r.m, mx);
+  for (int i = 1; i < N; ++i) mx = fmaxf(mx, x[i]);
+  const float mn = fmaxf(r.m, mx * c);   // c > 0: the largest x gives the largest y
   const float sc = fast_exp2(r.m - mn);  // one rescale per group, not per element
-  float e[N];
+  constexpr int LANES = N < 4 ? N : 4;   // independent accumulation chains
+  float es[LANES], ws[LANES];
 #pragma unroll
-  for (int i = 0; i < N; ++i) e[i] = fast_exp2(y[i] - mn);
-  // pairwise sums inside the group: shorter dependency chains, smaller rounding error
-  float es[N], ws[N];
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    es[i] = e[i];
-    ws[i] = y[i] * e[i];
+  for (int i = 0; i < LANES; ++i) {
+    const float e = fast_exp2(fmaf(x[i], c, -mn));
+    es[i] = e;
+    ws[i] = x[i] * e;
   }
 #pragma unroll
-  for (int h = N / 2; h > 0; h >>= 1) {
+  for (int i = LANES; i < N; ++i) {
+    const float e = fast_exp2(fmaf(x[i], c, -mn));
+    es[i % LANES] += e;
+    ws[i % LANES] = fmaf(x[i], e, ws[i % LANES]);
+  }
+#pragma unroll
+  for (int h = LANES / 2; h > 0; h >>= 1) {
 #pragma unroll
     for (int i = 0; i < h; ++i) {
       es[i] += es[i + h];
@@ -106,9 +111,9 @@ __device__ __forceinline__ void absorb(Running& r, const float (&y)[N]) {
   r.m = mn;
 }
 
-__device__ __forceinline__ void absorb_one(Running& r, float y) {
-  const float v[1] = {y};
-  absorb<1>(r, v);
+__device__ __forceinline__ void absorb_one(Running& r, float x, float c) {
+  const float v[1] = {x};
+  absorb<1>(r, v, c);
 }
 
 __device__ __forceinline__ Running merge(const Running& a, const Running& b) {
@@ -157,6 +162,26 @@ __device__ __forceinline__ float load_elem(const char* p, int64_t i) {
   }
 }
 
+// 16 bytes of logits -> VE raw values
+template <int DT>
+__device__ __forceinline__ void decode16_raw(const u32x4& v, float* y) {
+  if constexpr (DT == PRL_F32) {
+    y[0] = __uint_as_float(v.x);
+    y[1] = __uint_as_float(v.y);
+    y[2] = __uint_as_float(v.z);
+    y[3] = __uint_as_float(v.w);
+  } else {
+    y[0] = bf16_lo(v.x);
+    y[1] = bf16_hi(v.x);
+    y[2] = bf16_lo(v.y);
+    y[3] = bf16_hi(v.y);
+    y[4] = bf16_lo(v.z);
+    y[5] = bf16_hi(v.z);
+    y[6] = bf16_lo(v.w);
+    y[7] = bf16_hi(v.w);
+  }
+}
+
 // 16 bytes of logits -> VE scaled values y = x * c
 template <int DT>
 __device__ __forceinline__ void decode16(const u32x4& v, float c, float* y) {
@@ -189,8 +214,8 @@ __device__ __forceinline__ void reduce_range(const char* p, int64_t n, float c, 
   if (head > n) head = n;
   const int64_t nvec = (n - head) / VE;
   const int64_t tail0 = head + nvec * VE;
-  if (tid < head) absorb_one(r, c * load_elem<DT>(p, tid));
-  if (tail0 + tid < n) absorb_one(r, c * load_elem<DT>(p, tail0 + tid));
+  if (tid < head) absorb_one(r, load_elem<DT>(p, tid), c);
+  if (tail0 + tid < n) absorb_one(r, load_elem<DT>(p, tail0 + tid), c);
 
   const u32x4* vp = reinterpret_cast<const u32x4*>(p + head * ES);
   int64_t vi = tid;
@@ -205,15 +230,15 @@ __device__ __forceinline__ void reduce_range(const char* p, int64_t n, float c, 
       constexpr int GRP = UNR < 4 ? UNR : 4;
       float y[GRP * VE];
 #pragma unroll
-      for (int q = 0; q < GRP; ++q) decode16<DT>(a[q0 + q], c, y + q * VE);
-      absorb<GRP * VE>(r, y);
+      for (int q = 0; q < GRP; ++q) decode16_raw<DT>(a[q0 + q], y + q * VE);
+      absorb<GRP * VE>(r, y, c);
     }
   }
   for (; vi < nvec; vi += NT) {
     const u32x4 a0 = stream_load<PRL_FWD_NT_LOAD>(vp + vi);
     float y[VE];
-    decode16<DT>(a0, c, y);
-    absorb<VE>(r, y);
+    decode16_raw<DT>(a0, y);
+    absorb<VE>(r, y, c);
   }
 }
 
@@ -223,7 +248,7 @@ __device__ __forceinline__ void emit_token(const Running& r, float x_label, floa
   const float lse = (r.m + fast_log2(r.s)) * kLn2;
   if (lse_out) lse_out[t] = lse;
   if (lp) lp[t] = x_label * inv_temp - lse;
-  if (ent) ent[t] = lse - (r.w / r.s) * kLn2;
+  if (ent) ent[t] = lse - (r.w / r.s) * inv_temp;  // E[x] / temperature
 }
 
 __device__ __forceinline__ void emit_zero_row(int64_t V, int64_t t, float* lp, float* ent, float* lse_out) {
@@ -567,8 +592,8 @@ extern "C" int prl_logprob_entropy_fwd(const void* logits, int logits_dtype, int
   if (T == 0) return PRL_OK;
   PRL_REQUIRE(logits && ids, "logprob_entropy_fwd: logits and ids must not be NULL");
   PRL_REQUIRE(row_stride >= V, "logprob_entropy_fwd: row_stride %lld < V %lld", (long long)row_stride, (long long)V);
-  PRL_REQUIRE(temperature != 0.0f && temperature == temperature && temperature - temperature == 0.0f,
-              "logprob_entropy_fwd: temperature must be finite and non-zero");
+  PRL_REQUIRE(temperature > 0.0f && temperature - temperature == 0.0f,
+              "logprob_entropy_fwd: temperature must be finite and positive");
   PRL_REQUIRE(shift == 0 || shift == 1, "logprob_entropy_fwd: shift must be 0 or 1");
   PRL_REQUIRE(T < (int64_t)1 << 31, "logprob_entropy_fwd: T too large");
   const int es = logits_dtype == PRL_F32 ? 4 : 2;
@@ -627,8 +652,8 @@ extern "C" int prl_logprob_bwd(const void* logits, int logits_dtype, int64_t T, 
   if (T == 0) return PRL_OK;
   PRL_REQUIRE(logits && ids && lse && g && dlogits, "logprob_bwd: logits, ids, lse, g, dlogits must not be NULL");
   PRL_REQUIRE(row_stride >= V && out_row_stride >= V, "logprob_bwd: row strides must be >= V");
-  PRL_REQUIRE(temperature != 0.0f && temperature == temperature && temperature - temperature == 0.0f,
-              "logprob_bwd: temperature must be finite and non-zero");
+  PRL_REQUIRE(temperature > 0.0f && temperature - temperature == 0.0f,
+              "logprob_bwd: temperature must be finite and positive");
   PRL_REQUIRE(shift == 0 || shift == 1, "logprob_bwd: shift must be 0 or 1");
   const int esi = logits_dtype == PRL_F32 ? 4 : 2, eso = out_dtype == PRL_F32 ? 4 : 2;
   PRL_REQUIRE((reinterpret_cast<uintptr_t>(logits) % esi) == 0 && (reinterpret_cast<uintptr_t>(dlogits) % eso) == 0,

@@ -465,3 +465,111 @@ def test_tensors_across_ranks_without_gathering():
                 assert got[f"{k}/{name}"] == w[name]
             assert abs(got[f"{k}/mean"] - w["mean"]) <= 1e-5
             assert abs(got[f"{k}/std"] - w["std"]) <= 1e-4 * w["std"]
+
+
+# --------------------------------------------------------------------------- more corners of the boundary
+
+
+def test_plain_tensor_backward_shift0_and_batch_of_rows():
+    """selective_log_softmax on an ordinary [B, T, V] tensor (no shift, B > 1) is
+    differentiable like the reference's (src/prime_rl/trainer/rl/loss.py:27-30)."""
+    gen = torch.Generator().manual_seed(21)
+    x = torch.randn(3, 9, 517, generator=gen) * 2
+    idx = torch.randint(0, 517, (3, 9), generator=gen)
+    w = torch.randn(3, 9, generator=gen)
+    xr = x.clone().requires_grad_(True)
+    (O.selective_log_softmax(xr, idx) * w).sum().backward()
+    xd = x.to(DEV).requires_grad_(True)
+    lp = prl.selective_log_softmax(xd, idx.to(DEV))
+    (lp * w.to(DEV)).sum().backward()
+    close(lp, O.selective_log_softmax(x, idx))
+    close(xd.grad, xr.grad, atol=1e-6)
+    close(prl.compute_entropy(x.to(DEV)), O.compute_entropy(x))
+
+
+@pytest.mark.parametrize("din,dout", [(torch.float32, torch.bfloat16), (torch.bfloat16, torch.float32)])
+def test_mixed_storage_types_through_the_c_abi(din, dout):
+    """fp32 logits with a bf16 gradient and the reverse: same arithmetic, only the stores differ."""
+    from prime_rl_cse_amd import _capi as C
+
+    lib = C.load()
+    gen = torch.Generator().manual_seed(22)
+    t, v = 37, 4096 + 8
+    x = (torch.randn(t, v, generator=gen) * 3).to(din)
+    ids = torch.randint(0, v, (t,), generator=gen)
+    g = torch.randn(t, generator=gen)
+    g[5] = 0.0
+    xd, idd, gd = x.to(DEV), ids.to(DEV), g.to(DEV)
+    lp, ent, lse = (torch.empty(t, device=DEV) for _ in range(3))
+    st = C.stream_ptr(torch.device(DEV))
+    code = {torch.float32: C.PRL_F32, torch.bfloat16: C.PRL_BF16}
+    C.check(lib.prl_logprob_entropy_fwd(C.ptr(xd), code[din], t, v, v, C.ptr(idd), 0.7, 1, C.ptr(lp), C.ptr(ent),
+                                        C.ptr(lse), None, 0, st), "fwd")
+    out = torch.empty(t, v, dtype=dout, device=DEV)
+    C.check(lib.prl_logprob_bwd(C.ptr(xd), code[din], t, v, v, C.ptr(idd), C.ptr(lse), C.ptr(gd), None, 0.7, 1,
+                                C.ptr(out), code[dout], v, st), "bwd")
+    xr = x.float().clone().requires_grad_(True)
+    lpr = O.selective_log_softmax(O.shift_logits(xr.unsqueeze(0)) / 0.7, ids.unsqueeze(0))[0]
+    (lpr * g).sum().backward()
+    close(lp, lpr)
+    if dout == torch.bfloat16:
+        assert bf16_ulp_close(out.cpu(), xr.grad.to(torch.bfloat16), ulps=1, atol=1e-9)
+    else:
+        close(out, xr.grad, atol=1e-6)
+    assert not out[4].any() and not out[-1].any()  # g[5] == 0 zeroes row 4; the last row is dropped by the shift
+
+
+def test_infinite_and_nan_ratios_follow_autograd():
+    """A ratio of +inf is clipped in the loss but poisons its own gradient (0 * inf), exactly
+    as autograd does through exp; NaN inputs stay NaN."""
+    lp = torch.tensor([-1.0, -2.0, 100.0, -0.5, float("nan")])
+    old = torch.tensor([-1.1, -2.0, -100.0, -0.4, -1.0])
+    adv = torch.tensor([1.0, -1.0, 0.5, 2.0, 1.0])
+    mask = torch.tensor([True, True, True, False, True])
+    ref_lp = lp.clone().requires_grad_(True)
+    l_ref, a_ref = O.compute_loss([ref_lp[:3], ref_lp[3:]], [old[:3], old[3:]], [adv[:3], adv[3:]],
+                                  [mask[:3], mask[3:]], O.LossConfig(), 4.0)
+    l_ref.backward()
+    dlp = lp.to(DEV).requires_grad_(True)
+    l, a = prl.compute_loss([dlp[:3], dlp[3:]], [old.to(DEV)[:3], old.to(DEV)[3:]], [adv.to(DEV)[:3], adv.to(DEV)[3:]],
+                            [mask.to(DEV)[:3], mask.to(DEV)[3:]], prl.LossConfig(), 4.0)
+    l.backward()
+    close(l, l_ref.detach())
+    close(dlp.grad, ref_lp.grad)
+    assert dlp.grad[2].isnan() and ref_lp.grad[2].isnan() and dlp.grad[3] == 0
+    for k in a:
+        close(a[k], a_ref[k].detach())
+
+
+def test_sequence_mode_full_size():
+    """Sequence-level ratios at the benchmark shape, bf16 logits."""
+    t, v = 2048, 151936
+    gen = torch.Generator().manual_seed(31)
+    lengths = [100, 156, 128, 128, 256, 64, 64, 128, 1024]
+    ids, pos, mask = make_packed_row(gen, lengths, 0, v, mask_p=0.5)
+    logits = torch.empty(1, t, v, dtype=torch.bfloat16)
+    for r in range(0, t, 256):
+        logits[0, r : r + 256] = (torch.randn(256, v, generator=gen) * 2.0).to(torch.bfloat16)
+    adv = torch.randn(t, generator=gen)
+    b = lambda x: x.unsqueeze(0)
+    with torch.no_grad():
+        lp0 = O.selective_log_softmax(O.shift_logits(logits.float()), b(ids))[0]
+    old = lp0 + 0.01 * torch.randn(t, generator=gen)
+    cfg = prl.LossConfig(ratio_type="sequence", ratio_length_norm=True, clip_ratio=1.05)
+    want = O.policy_epilogue(logits, b(ids), b(pos), b(adv), b(old), b(mask), 1.0, cfg, len(lengths))
+    dl = logits.to(DEV).requires_grad_(True)
+    loss, aux = prl.policy_loss(dl, b(ids).to(DEV), b(pos).to(DEV), b(adv).to(DEV), b(old).to(DEV), b(mask).to(DEV),
+                                1.0, cfg, len(lengths))
+    loss.backward()
+    n = len(lengths)
+    assert int(aux["n_seg"].item()) == n
+    close(loss, want["loss"])
+    close(aux["importance_ratio"][:n], want["importance_ratio"])
+    close(aux["is_clipped"][:n], want["is_clipped"])
+    grad_close(dl.grad, want["dlogits"])
+
+
+def test_negative_temperature_is_refused():
+    x = torch.randn(1, 4, 16, device=DEV)
+    with pytest.raises(RuntimeError, match="positive"):
+        prl.selective_log_softmax(prl.shift_logits(x) / -1.0, torch.zeros(1, 4, dtype=torch.long, device=DEV))
