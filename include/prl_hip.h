@@ -146,11 +146,16 @@ int prl_grpo_loss(const float* lp, const float* old, const float* adv, const uin
  * compute_entropy).  The per-sample arrays (ratio, clipped, is_clipped in
  * sequence mode, seg_loss) need room for T / 2 + 1 entries, seg_start for
  * T + 1.  entropy, ratio, clipped, is_clipped, g and seg_id may be NULL.
+ * skip_masked = 1 leaves tokens whose mask is 0 unscored: their logits row is
+ * not read and their logprob, entropy and lse come back as 0.  Loss, gradient
+ * and every masked statistic are unchanged, because the reference uses those
+ * values only under the mask (loss.py:93, :104; train.py:313-315); with prompts
+ * masked out this removes their share of the forward's HBM traffic.
  */
 int prl_policy_forward(const void* logits, int logits_dtype, int64_t T, int64_t V, int64_t row_stride,
                        const int64_t* ids, const int64_t* pos, const float* adv, const float* old,
-                       const uint8_t* mask, float temperature, int ratio_type, int length_norm, float clip_ratio,
-                       float loss_scale, float* logprob, float* entropy, float* lse, float* loss, float* ratio,
+                       const uint8_t* mask, int skip_masked, float temperature, int ratio_type, int length_norm,
+                       float clip_ratio, float loss_scale, float* logprob, float* entropy, float* lse, float* loss, float* ratio,
                        float* clipped, float* is_clipped, float* g, float* seg_loss, int32_t* seg_id,
                        int64_t* seg_start, int32_t* n_seg, void* workspace, size_t workspace_bytes, void* stream);
 

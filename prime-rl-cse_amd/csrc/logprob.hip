@@ -251,6 +251,12 @@ __device__ __forceinline__ void emit_token(const Running& r, float x_label, floa
   if (ent) ent[t] = lse - (r.w / r.s) * inv_temp;  // E[x] / temperature
 }
 
+__device__ __forceinline__ void emit_skipped(int64_t t, float* lp, float* ent, float* lse_out) {
+  if (lse_out) lse_out[t] = 0.0f;
+  if (lp) lp[t] = 0.0f;
+  if (ent) ent[t] = 0.0f;
+}
+
 __device__ __forceinline__ void emit_zero_row(int64_t V, int64_t t, float* lp, float* ent, float* lse_out) {
   // an all-zero row: every probability is 1/V
   const float l = logf((float)V);
@@ -263,8 +269,8 @@ __device__ __forceinline__ void emit_zero_row(int64_t V, int64_t t, float* lp, f
 template <int DT, int NT>
 __global__ __launch_bounds__(NT) void k_logprob_fwd(const char* __restrict__ logits, int64_t V, int64_t stride_bytes,
                                                     const int64_t* __restrict__ ids, float inv_temp, int shift,
-                                                    float* __restrict__ lp, float* __restrict__ ent,
-                                                    float* __restrict__ lse_out) {
+                                                    const uint8_t* __restrict__ skip, float* __restrict__ lp,
+                                                    float* __restrict__ ent, float* __restrict__ lse_out) {
   constexpr int NW = NT / kWave;
   __shared__ float lds[3 * NW];
 #if PRL_FWD_REVERSE
@@ -272,6 +278,10 @@ __global__ __launch_bounds__(NT) void k_logprob_fwd(const char* __restrict__ log
 #else
   const int64_t t = blockIdx.x;
 #endif
+  if (skip && skip[t] == 0) {  // a token nobody will look at: its row is not read
+    if (threadIdx.x == 0) emit_skipped(t, lp, ent, lse_out);
+    return;
+  }
   if (shift && t == 0) {
     if (threadIdx.x == 0) emit_zero_row(V, t, lp, ent, lse_out);
     return;
@@ -292,12 +302,14 @@ __global__ __launch_bounds__(NT) void k_logprob_fwd(const char* __restrict__ log
 template <int DT, int NT>
 __global__ __launch_bounds__(NT) void k_logprob_fwd_part(const char* __restrict__ logits, int64_t V,
                                                          int64_t stride_bytes, int shift, float inv_temp, int nsplit,
-                                                         int64_t chunk, float4* __restrict__ part) {
+                                                         int64_t chunk, const uint8_t* __restrict__ skip,
+                                                         float4* __restrict__ part) {
   constexpr int NW = NT / kWave;
   __shared__ float lds[3 * NW];
   const int64_t t = blockIdx.x / nsplit;
   const int k = (int)(blockIdx.x % nsplit);
   if (shift && t == 0) return;
+  if (skip && skip[t] == 0) return;
   constexpr int ES = DT == PRL_F32 ? 4 : 2;
   const int64_t e0 = k * chunk;
   int64_t n = V - e0;
@@ -311,10 +323,14 @@ __global__ __launch_bounds__(NT) void k_logprob_fwd_part(const char* __restrict_
 template <int DT>
 __global__ void k_logprob_fwd_merge(const char* __restrict__ logits, int64_t T, int64_t V, int64_t stride_bytes,
                                     const int64_t* __restrict__ ids, float inv_temp, int shift, int nsplit,
-                                    const float4* __restrict__ part, float* __restrict__ lp,
-                                    float* __restrict__ ent, float* __restrict__ lse_out) {
+                                    const uint8_t* __restrict__ skip, const float4* __restrict__ part,
+                                    float* __restrict__ lp, float* __restrict__ ent, float* __restrict__ lse_out) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= T) return;
+  if (skip && skip[t] == 0) {
+    emit_skipped(t, lp, ent, lse_out);
+    return;
+  }
   if (shift && t == 0) {
     emit_zero_row(V, t, lp, ent, lse_out);
     return;
@@ -578,10 +594,24 @@ extern "C" size_t prl_logprob_workspace_bytes(int64_t T, int64_t V) {
   return ns > 1 ? (size_t)T * ns * sizeof(float4) : 0;
 }
 
+namespace prl {
+int logprob_fwd_impl(const void* logits, int logits_dtype, int64_t T, int64_t V, int64_t row_stride,
+                     const int64_t* ids, float temperature, int shift, const uint8_t* skip, float* logprob,
+                     float* entropy, float* lse, void* workspace, size_t workspace_bytes, void* stream);
+}
+
 extern "C" int prl_logprob_entropy_fwd(const void* logits, int logits_dtype, int64_t T, int64_t V,
                                        int64_t row_stride, const int64_t* ids, float temperature, int shift,
                                        float* logprob, float* entropy, float* lse, void* workspace,
                                        size_t workspace_bytes, void* stream) {
+  return logprob_fwd_impl(logits, logits_dtype, T, V, row_stride, ids, temperature, shift, nullptr, logprob, entropy,
+                          lse, workspace, workspace_bytes, stream);
+}
+
+// `skip`: optional 0/1 per token; tokens with 0 are not scored (their row is not read, their outputs are 0)
+int prl::logprob_fwd_impl(const void* logits, int logits_dtype, int64_t T, int64_t V, int64_t row_stride,
+                          const int64_t* ids, float temperature, int shift, const uint8_t* skip, float* logprob,
+                          float* entropy, float* lse, void* workspace, size_t workspace_bytes, void* stream) {
   clear_error();
   PRL_REQUIRE(T >= 0 && V >= 1, "logprob_entropy_fwd: need T >= 0 and V >= 1 (got T=%lld V=%lld)", (long long)T,
               (long long)V);
@@ -610,10 +640,10 @@ extern "C" int prl_logprob_entropy_fwd(const void* logits, int logits_dtype, int
   if (ns == 1) {
     if (logits_dtype == PRL_F32)
       hipLaunchKernelGGL((k_logprob_fwd<PRL_F32, kFwdThreads>), dim3((unsigned)T), dim3(kFwdThreads), 0, st, lg, V, sb,
-                         ids, inv_temp, shift, logprob, entropy, lse);
+                         ids, inv_temp, shift, skip, logprob, entropy, lse);
     else
       hipLaunchKernelGGL((k_logprob_fwd<PRL_BF16, kFwdThreads>), dim3((unsigned)T), dim3(kFwdThreads), 0, st, lg, V,
-                         sb, ids, inv_temp, shift, logprob, entropy, lse);
+                         sb, ids, inv_temp, shift, skip, logprob, entropy, lse);
     PRL_CHECK_LAUNCH("logprob_entropy_fwd");
     return PRL_OK;
   }
@@ -623,16 +653,16 @@ extern "C" int prl_logprob_entropy_fwd(const void* logits, int logits_dtype, int
   const unsigned mblk = (unsigned)((T + 255) / 256);
   if (logits_dtype == PRL_F32) {
     hipLaunchKernelGGL((k_logprob_fwd_part<PRL_F32, kFwdThreads>), dim3(nblk), dim3(kFwdThreads), 0, st, lg, V, sb,
-                       shift, inv_temp, ns, chunk, part);
+                       shift, inv_temp, ns, chunk, skip, part);
     PRL_CHECK_LAUNCH("logprob_entropy_fwd(part)");
     hipLaunchKernelGGL((k_logprob_fwd_merge<PRL_F32>), dim3(mblk), dim3(256), 0, st, lg, T, V, sb, ids, inv_temp,
-                       shift, ns, part, logprob, entropy, lse);
+                       shift, ns, skip, part, logprob, entropy, lse);
   } else {
     hipLaunchKernelGGL((k_logprob_fwd_part<PRL_BF16, kFwdThreads>), dim3(nblk), dim3(kFwdThreads), 0, st, lg, V, sb,
-                       shift, inv_temp, ns, chunk, part);
+                       shift, inv_temp, ns, chunk, skip, part);
     PRL_CHECK_LAUNCH("logprob_entropy_fwd(part)");
     hipLaunchKernelGGL((k_logprob_fwd_merge<PRL_BF16>), dim3(mblk), dim3(256), 0, st, lg, T, V, sb, ids, inv_temp,
-                       shift, ns, part, logprob, entropy, lse);
+                       shift, ns, skip, part, logprob, entropy, lse);
   }
   PRL_CHECK_LAUNCH("logprob_entropy_fwd(merge)");
   return PRL_OK;

@@ -315,7 +315,7 @@ class _PolicyLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, logits, input_ids, position_ids, advantages, old_logprobs, loss_mask, temperature,
-                loss_config, loss_scale):
+                loss_config, loss_scale, skip_masked):
         dev = C.require_device(logits, input_ids, position_ids, advantages, old_logprobs, loss_mask)
         lib = C.load()
         logits = _rows(logits)
@@ -340,7 +340,7 @@ class _PolicyLoss(torch.autograd.Function):
             C.check(
                 lib.prl_policy_forward(
                     C.ptr(logits), C.dtype_code(logits), t, v, logits.stride(1), C.ptr(ids), C.ptr(pos), C.ptr(adv),
-                    C.ptr(old), C.ptr(mask), temperature, _ratio_code(loss_config),
+                    C.ptr(old), C.ptr(mask), int(bool(skip_masked)), temperature, _ratio_code(loss_config),
                     int(bool(loss_config.ratio_length_norm)), float(loss_config.clip_ratio), float(loss_scale),
                     at(0), at(1), at(2), at(8), at(4), at(5), at(6), at(3), at(7), None, C.c_void_p(ip),
                     C.c_void_p(ip + 8 * (t + 1)), C.ptr(ws), ws_bytes, C.stream_ptr(dev),
@@ -363,7 +363,7 @@ class _PolicyLoss(torch.autograd.Function):
         logits, ids, lse, g = ctx.saved_tensors
         gscale = grad_loss.to(torch.float32).reshape(1).contiguous()
         d = _launch_bwd(logits, ids, lse, g, gscale, ctx.temperature, True)
-        return (d,) + (None,) * 8
+        return (d,) + (None,) * 9
 
 
 def policy_loss(
@@ -376,6 +376,7 @@ def policy_loss(
     temperature: float,
     loss_config: Any,
     loss_scale: float,
+    skip_masked: bool = False,
 ) -> tuple[Tensor, dict[str, Tensor]]:
     """One micro-batch of the trainer's hot loop from the model's logits to a
     differentiable loss (src/prime_rl/trainer/rl/train.py:285-303) in one call
@@ -386,13 +387,15 @@ def policy_loss(
     `logprobs`, `entropy` (fp32 [1, T]), the three ratio tensors of
     `compute_loss`, and the device-side sample table (`seg_start`, `n_seg`).
     In sequence mode the ratio tensors have room for T // 2 + 1 samples, of
-    which the first `n_seg` are filled.  Calling `.backward()` on the loss runs
+    which the first `n_seg` are filled.  `skip_masked=True` does not score
+    tokens whose mask is False (their `logprobs` and `entropy` are 0, their
+    logits are never read); loss, gradient and masked statistics are the same.  Calling `.backward()` on the loss runs
     one more pass over the logits and leaves dlogits in `logits.grad`."""
     if logits.ndim != 3 or logits.shape[0] != 1:
         raise ValueError(f"policy_loss takes one packed row, logits [1, T, V]; got {tuple(logits.shape)}")
     loss, lp, ent, ratio, clipped, is_clipped, seg_start, n_seg = _PolicyLoss.apply(
         logits, input_ids, position_ids, advantages, old_logprobs, loss_mask, float(temperature), loss_config,
-        float(loss_scale),
+        float(loss_scale), bool(skip_masked),
     )
     return loss, {
         "logprobs": lp,

@@ -135,7 +135,7 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, micro_batches
         mb = to_device(host_mb, device)
         logits = forward(model, mb["input_ids"], mb["position_ids"])
         loss, aux = policy_loss(logits, mb["input_ids"], mb["position_ids"], mb["advantages"], mb["logprobs"],
-                                mb["loss_mask"], mb["temperature"], loss_config, loss_scale)
+                                mb["loss_mask"], mb["temperature"], loss_config, loss_scale, skip_masked=True)
         del logits
         loss.backward()
         mask = mb["loss_mask"]

@@ -75,7 +75,7 @@ def test_bad_arguments_are_rejected_with_a_message():
     assert lib.prl_stats_pass(4, bad, 0, 2, one, null) == -1
     off = (ctypes.c_int64 * 5)()
     assert lib.prl_stats_layout(3, off) == 0 and off[4] == lib.prl_stats_workspace_bytes(3) and off[4] % 8 == 0
-    assert lib.prl_policy_forward(one, 0, 4, 8, 8, one, one, one, one, one, 1.0, 0, 0, 8.0, 1.0, null, one, one, one,
+    assert lib.prl_policy_forward(one, 0, 4, 8, 8, one, one, one, one, one, 0, 1.0, 0, 0, 8.0, 1.0, null, one, one, one,
                                   one, one, one, one, one, null, one, one, null, 0, null) == -1
     # size queries need no device
     assert lib.prl_logprob_workspace_bytes(2048, 151936) == 0

@@ -573,3 +573,29 @@ def test_negative_temperature_is_refused():
     x = torch.randn(1, 4, 16, device=DEV)
     with pytest.raises(RuntimeError, match="positive"):
         prl.selective_log_softmax(prl.shift_logits(x) / -1.0, torch.zeros(1, 4, dtype=torch.long, device=DEV))
+
+
+def test_skip_masked_changes_nothing_that_is_used():
+    """Not scoring masked-out tokens leaves the loss, the gradient and every masked statistic as they were."""
+    gen = torch.Generator().manual_seed(41)
+    lengths, vocab = [50, 30, 48], 4096
+    ids, pos, mask = make_packed_row(gen, lengths, 0, vocab, mask_p=0.5)
+    t = sum(lengths)
+    logits = (torch.randn(1, t, vocab, generator=gen) * 2).to(torch.bfloat16)
+    adv, old = torch.randn(1, t, generator=gen), -8.0 + 0.1 * torch.randn(1, t, generator=gen)
+    b = lambda x: x.unsqueeze(0).to(DEV)
+    outs = []
+    for skip in (False, True):
+        for rtype in ("token", "sequence"):
+            dl = logits.to(DEV).requires_grad_(True)
+            loss, aux = prl.policy_loss(dl, b(ids), b(pos), adv.to(DEV), old.to(DEV), b(mask), 0.8,
+                                        prl.LossConfig(ratio_type=rtype), 77, skip_masked=skip)
+            loss.backward()
+            outs.append((loss, aux, dl.grad))
+    m = mask.to(DEV)
+    for (l0, a0, g0), (l1, a1, g1) in ((outs[0], outs[2]), (outs[1], outs[3])):
+        assert torch.equal(l0, l1) and torch.equal(g0, g1)
+        assert torch.equal(a0["logprobs"][0][m], a1["logprobs"][0][m])
+        assert torch.equal(a0["entropy"][0][m], a1["entropy"][0][m])
+        assert not a1["logprobs"][0][~m].any() and not a1["entropy"][0][~m].any()
+        assert a0["logprobs"][0][~m].abs().min() > 0
