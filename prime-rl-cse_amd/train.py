@@ -1,0 +1,165 @@
+"""RL trainer entry point:  torchrun ... -m prime_rl_cse_amd.train @ train.toml
+
+The loop of src/prime_rl/trainer/rl/train.py:55-466 on MI355X: FSDP2 over RCCL
+for the transformer body, this package's HIP path for everything after the LM
+head, weight publication on a side stream.  Left out on purpose: W&B, full
+(resumable) checkpoints, LoRA, MoE load-balance statistics, the torch profiler
+hooks.
+"""
+
+from __future__ import annotations
+
+import statistics
+import time
+from pathlib import Path
+from typing import Any
+
+import torch
+import torch.distributed as dist
+
+from . import perf
+from . import trainer as T
+from .data import DataLoader, FakeDataLoader
+from .optim import setup_optimizer, setup_scheduler
+from .settings import RLTrainerConfig, parse_argv
+from .weights import WeightPublisher, get_weight_ckpt_model_path, get_weights_dir
+from .world import get_world
+
+DTYPES = {"bfloat16": torch.bfloat16, "float32": torch.float32}
+
+
+def log(msg: str) -> None:
+    if get_world().is_master:
+        print(msg, flush=True)
+
+
+def build_model(config: RLTrainerConfig, device: torch.device, mesh: Any, dtype: torch.dtype | None = None):
+    mc = config.model
+    attn = "sdpa"  # flash-attn is a CUDA package; PyTorch-ROCm's SDPA takes the packed rows' block-diagonal mask
+    if Path(mc.name).is_dir():  # a local checkpoint directory in HF layout
+        from transformers import AutoConfig, AutoModelForCausalLM
+
+        cfg = AutoConfig.from_pretrained(mc.name)
+        cfg._attn_implementation, cfg.use_cache = attn, False
+        if mc.debug.num_layers is not None:
+            cfg.num_hidden_layers = min(mc.debug.num_layers, cfg.num_hidden_layers)
+        model = AutoModelForCausalLM.from_pretrained(mc.name, config=cfg, dtype=dtype or DTYPES[mc.optimization_dtype])
+        model.to(device)
+    elif mc.name in T.MODEL_DIMS:
+        cfg = T.model_config(mc.name, attn=attn, num_layers=mc.debug.num_layers)
+        model = T.get_model(cfg, device, dtype or DTYPES[mc.optimization_dtype])
+        log(f"{mc.name}: no weights on this machine, training from a random initialisation")
+    else:
+        raise ValueError(f"model {mc.name!r} is neither a local directory nor one of {sorted(T.MODEL_DIMS)}")
+    if mc.ac is not None:
+        from torch.distributed.algorithms._checkpoint.checkpoint_wrapper import checkpoint_wrapper
+
+        for i, (name, block) in enumerate(list(model.model.layers.named_children())):
+            if i % mc.ac.freq == 0:
+                model.model.layers.register_module(name, checkpoint_wrapper(block, preserve_rng_state=False))
+    T.setup_fsdp(model, mesh, DTYPES[mc.reduce_dtype], mc.reshard_after_forward)
+    return model, cfg
+
+
+def print_benchmark(history: list[dict[str, float]]) -> dict[str, dict[str, float]]:
+    """Mean, std, min, max of throughput and step time over all steps but the first
+    (src/prime_rl/trainer/utils.py:133-192)."""
+    rows = history[1:]
+    out = {}
+    for key in ("perf/mfu", "perf/throughput", "time/step", "perf/peak_memory"):
+        vals = [r[key] for r in rows if key in r]
+        if vals:
+            out[key] = {"mean": statistics.fmean(vals), "std": statistics.stdev(vals) if len(vals) > 1 else 0.0,
+                        "min": min(vals), "max": max(vals)}
+    log("Benchmark (first step excluded)")
+    for key, v in out.items():
+        log(f"  {key:18s} {v['mean']:.4g} +- {v['std']:.2g} [{v['min']:.4g}, {v['max']:.4g}]")
+    return out
+
+
+def train(config: RLTrainerConfig) -> list[dict[str, float]]:
+    world = get_world()
+    torch.cuda.set_device(world.local_rank)
+    device = torch.device("cuda", world.local_rank)
+    if config.model.cp > 1:
+        raise ValueError("CP is not supported for RL. No reason it shouldn't, we just didn't test it.")
+    mesh = T.init_distributed(device)
+    log(f"Starting RL trainer on {world}")
+    model, model_cfg = build_model(config, device, mesh)
+    optimizer = setup_optimizer(config.optim, model)
+    scheduler = setup_scheduler(optimizer, config.scheduler, config.max_steps, config.optim.lr)
+    publisher = WeightPublisher(config.output_dir, config.weights.interval,
+                                config.ckpt.interval if config.ckpt else None, config.async_level, device)
+    loader = FakeDataLoader(config.data.fake) if config.data.fake else DataLoader(config.output_dir, 0)
+    logprob_model = None
+    if config.recompute_logprobs:
+        logprob_model, _ = build_model(config, device, mesh, dtype=torch.bfloat16)
+        logprob_model.requires_grad_(False)
+    snapshots: dict[int, dict[str, torch.Tensor]] = {}
+    device_name = torch.cuda.get_device_name(device)
+    counter = None
+    history: list[dict[str, float]] = []
+    step = 0
+    while config.max_steps is None or step < config.max_steps:
+        t_step = time.perf_counter()
+        t_save = 0.0
+        if step > 0:  # weights of step N go to the inference side while step N + 1 trains
+            t0 = time.perf_counter()
+            publisher.publish(model, step)
+            t_save = time.perf_counter() - t0
+        if logprob_model is not None:
+            snapshots[step] = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        t0 = time.perf_counter()
+        loader.wait_for_batch()
+        micro_batches = loader.get_batch()
+        t_data = time.perf_counter() - t0
+        t_recompute = 0.0
+        errors = None
+        if logprob_model is not None:
+            t0 = time.perf_counter()
+            infer_step = max(step - config.async_level, 0)
+            logprob_model.load_state_dict(snapshots[infer_step])
+            if infer_step == step - config.async_level:
+                del snapshots[infer_step]
+            errors = T.recompute_logprobs(logprob_model, micro_batches, device)
+            t_recompute = time.perf_counter() - t0
+        publisher.guard_parameters()
+        samples = (config.data.fake.batch_size // world.world_size) if config.data.fake else None
+        res = T.train_step(model, optimizer, micro_batches, config.loss, config.optim.max_norm, device, scheduler,
+                           samples=samples, recomputed_errors=errors)
+        publisher.maybe_clean(step)
+        seq_len = micro_batches[0]["input_ids"].shape[1]
+        if counter is None:
+            counter = perf.PerfCounter(model_cfg, seq_len, device_name=device_name, world_size=world.world_size)
+        counter.count_tokens(res.tokens * world.world_size)
+        step_time = time.perf_counter() - t_step
+        row = {"step": step, "time/step": step_time, "time/forward_backward": res.seconds, "time/load_data": t_data,
+               "time/save_weights": t_save, "time/compute_logprobs": t_recompute,
+               "perf/throughput": counter.get_tokens_per_second() or 0.0, "perf/mfu": counter.get_mfu() or 0.0,
+               "perf/peak_memory": torch.cuda.max_memory_allocated(device) / 1024**3,
+               "optim/lr": optimizer.param_groups[0]["lr"], "optim/grad_norm": res.grad_norm, **res.stats}
+        history.append(row)
+        log(f"Step {step} | Time: {step_time:.2f}s | Loss: {res.stats.get('loss/mean', float('nan')):.4f} | "
+            f"Entropy: {res.stats.get('entropy/mean', float('nan')):.4f} | "
+            f"Importance Ratio: {res.stats.get('importance_ratio/mean', float('nan')):.4f} | "
+            f"Grad. Norm: {res.grad_norm:.4f} | LR: {row['optim/lr']:.2e} | "
+            f"Throughput: {row['perf/throughput']:.0f} tokens/s | MFU: {row['perf/mfu']:.1f}% | "
+            f"Peak Mem.: {row['perf/peak_memory']:.1f} GiB")
+        step += 1
+    if step > 0:  # the final weights, as the orchestrator waits for them
+        publisher.publish(model, step)
+    publisher.wait_all()
+    if config.bench and len(history) > 1:
+        print_benchmark(history)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+    return history
+
+
+def main() -> None:
+    train(parse_argv(RLTrainerConfig))
+
+
+if __name__ == "__main__":
+    main()

@@ -122,9 +122,12 @@ def local_loss_scale(micro_batches: list[MicroBatch], loss_config: LossConfig) -
 
 def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, micro_batches: list[MicroBatch],
                loss_config: LossConfig, max_norm: float = 1.0, device: torch.device | str = "cuda",
-               scheduler: Any = None, samples: int | None = None) -> StepResult:
+               scheduler: Any = None, samples: int | None = None,
+               recomputed_errors: list[Tensor] | None = None) -> StepResult:
     """One optimizer step over this rank's micro-batches
-    (src/prime_rl/trainer/rl/train.py:259-364)."""
+    (src/prime_rl/trainer/rl/train.py:259-364).  `recomputed_errors` are the
+    per-micro-batch tensors `recompute_logprobs` returned; they are logged as
+    `recomputed_logprob_error` (train.py:316-318)."""
     t0 = time.perf_counter()
     loss_scale = local_loss_scale(micro_batches, loss_config)
     tensors = Tensors()
@@ -143,6 +146,8 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, micro_batches
         tensors.add("old_probs", mb["logprobs"], mask, exp=True)
         tensors.add("entropy", aux["entropy"], mask)
         tensors.add("loss", loss.detach().reshape(1))
+        if recomputed_errors is not None:
+            tensors.add("recomputed_logprob_error", recomputed_errors[step_idx], mask)
         if loss_config.ratio_type == "token":
             for key in ("importance_ratio", "clipped_importance_ratio", "is_clipped"):
                 tensors.add(key, aux[key], mask)
@@ -162,6 +167,27 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, micro_batches
         samples = len(micro_batches)
     return StepResult(loss=stats.get("loss/mean", float("nan")), grad_norm=float(grad_norm), stats=stats,
                       seconds=seconds, tokens=tokens, samples=samples)
+
+
+@torch.no_grad()
+def recompute_logprobs(logprob_model: nn.Module, micro_batches: list[MicroBatch],
+                       device: torch.device | str = "cuda") -> list[Tensor]:
+    """Replace every micro-batch's sampler log-probabilities by the ones
+    `logprob_model` assigns (the trainer's optional recompute pass,
+    src/prime_rl/trainer/rl/train.py:227-245).  Returns, per micro-batch, the
+    device tensor exp(recomputed - sampler) that the trainer logs as
+    `recomputed_logprob_error`.  Same single pass over the logits as the training
+    forward; nothing is kept for a backward."""
+    from .loss import selective_log_softmax, shift_logits
+
+    errors = []
+    for mb in micro_batches:
+        ids = mb["input_ids"].to(device)
+        logits = forward(logprob_model, ids, mb["position_ids"].to(device))
+        lp = selective_log_softmax(shift_logits(logits) / mb["temperature"], ids)
+        errors.append(torch.exp(lp - mb["logprobs"].to(device)))
+        mb["logprobs"] = lp.cpu()
+    return errors
 
 
 def setup_optimizer(model: nn.Module, lr: float = 1e-6, weight_decay: float = 0.01,

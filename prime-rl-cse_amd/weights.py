@@ -1,0 +1,216 @@
+"""Trainer -> inference weight publication on a side HIP stream
+(counterpart of src/prime_rl/trainer/weights.py:96-255).
+
+The reference gathers every parameter on the compute stream, copies it to the
+host with a blocking copy, runs a barrier, and only then lets the step go on
+(`weights.py:130-143`, called at `trainer/rl/train.py:163-166`).  Here:
+
+  1. SNAPSHOT  on a side stream, ordered after the optimizer step by an event:
+               every local shard is cast to bf16 into memory of its own.  The
+               compute stream only ever waits for this (a read of 1/W of the
+               model), and only if it reaches the next optimizer step first.
+  2. GATHER    on the side stream: the bf16 shards are all-gathered over RCCL
+               (after the downcast, as the reference does, so half the bytes
+               travel), overlapping the next step's forward and backward.
+  3. COPY-OUT  rank 0 copies the gathered tensors into pinned host memory with
+               asynchronous copies on the side stream and records an event.
+  4. WRITE     a host thread waits for that event, writes `pytorch_model.tmp`
+               with torch.save and renames it to `pytorch_model.bin`
+               (`weights.py:169-174`): the file layout, the atomic rename and the
+               directory scheme `weights/step_N/` are the reference's, so its
+               orchestrator and inference worker read the result unchanged.
+
+Consumers on the same node that can take device memory register a callback
+with `add_device_subscriber`; it is called on the side stream with the gathered
+bf16 tensors before the copy-out, which is where a device-to-device hand-off to
+an inference engine plugs in.
+"""
+
+from __future__ import annotations
+
+import contextlib
+import shutil
+import threading
+from pathlib import Path
+from typing import Any, Callable
+
+import torch
+import torch.distributed as dist
+from torch import Tensor, nn
+
+try:  # DTensor is present in every torch this package supports; keep CPU-only tools importable regardless
+    from torch.distributed.tensor import DTensor
+except Exception:  # pragma: no cover
+    DTensor = ()  # type: ignore[assignment]
+
+from .world import get_world
+
+
+def get_weights_dir(output_dir: Path) -> Path:
+    return Path(output_dir) / "weights"
+
+
+def get_step_path(path: Path, step: int) -> Path:
+    return Path(path) / f"step_{step}"
+
+
+def get_weight_ckpt_model_path(weights_dir: Path, step: int) -> Path:
+    return Path(weights_dir) / f"step_{step}" / "pytorch_model.bin"
+
+
+def wait_for_weight_checkpoint(weights_dir: Path, step: int, interval: float = 1.0, timeout: float | None = None):
+    """What the orchestrator does before it tells the inference server to reload
+    (src/prime_rl/orchestrator/utils.py:53-55)."""
+    from .data import wait_for_path
+
+    wait_for_path(get_weight_ckpt_model_path(weights_dir, step), interval, timeout)
+
+
+class PendingPublication:
+    """Handle of one publication in flight."""
+
+    def __init__(self, step: int, path: Path):
+        self.step, self.path = step, path
+        self.snapshot_done: Any = None  # event: local shards copied, parameters may change again
+        self._thread: threading.Thread | None = None
+        self.error: BaseException | None = None
+
+    def wait(self, timeout: float | None = None) -> Path:
+        """Block until the file is in place (rank 0) or the gather has been issued (other ranks)."""
+        if self._thread is not None:
+            self._thread.join(timeout)
+            if self._thread.is_alive():
+                raise TimeoutError(f"weight publication of step {self.step} still running")
+        if self.error is not None:
+            raise self.error
+        return self.path
+
+
+class WeightPublisher:
+    """Publishes HF-compatible bf16 weight files without stalling the step."""
+
+    def __init__(self, output_dir: Path, interval: int | None = None, ckpt_interval: int | None = None,
+                 async_level: int = 2, device: torch.device | str | None = None):
+        self.weights_dir = get_weights_dir(output_dir)
+        self.interval, self.ckpt_interval, self.async_level = interval, ckpt_interval, async_level
+        self.device = torch.device(device) if device is not None else None
+        self._is_master = get_world().is_master
+        self._stream: Any = None
+        self._subscribers: list[Callable[[dict[str, Tensor], int], None]] = []
+        self._pending: list[PendingPublication] = []
+
+    # ------------------------------------------------------------------ plumbing
+
+    def add_device_subscriber(self, fn: Callable[[dict[str, Tensor], int], None]) -> None:
+        """`fn(state, step)` runs on the publication stream with the gathered bf16 tensors still on the device."""
+        self._subscribers.append(fn)
+
+    def _side_stream(self):
+        if self.device is None or self.device.type != "cuda":
+            return None
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=self.device)  # default priority on purpose
+        return self._stream
+
+    # ------------------------------------------------------------------ publication
+
+    def publish(self, model: nn.Module, step: int, dtype: torch.dtype = torch.bfloat16, tokenizer: Any = None,
+                state_dict: dict[str, Tensor] | None = None) -> PendingPublication:
+        """Start publishing the current weights as `weights/step_<step>/pytorch_model.bin`.
+
+        Returns at once.  Call `guard_parameters()` (or `pending.snapshot_done.synchronize()`) before the next
+        in-place update of the parameters; the trainer loop in this package does."""
+        pending = PendingPublication(step, get_weight_ckpt_model_path(self.weights_dir, step))
+        state = state_dict if state_dict is not None else model.state_dict()
+        side = self._side_stream()
+        ctx = torch.cuda.stream(side) if side is not None else contextlib.nullcontext()
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream(self.device))  # after the optimizer step
+        with ctx, torch.no_grad():
+            # 1. snapshot: bf16 copies of the local shards
+            snap = {k: (v.detach().to(dtype) if v.is_floating_point() else v.detach().clone()) for k, v in state.items()}
+            if side is not None:
+                pending.snapshot_done = torch.cuda.Event()
+                pending.snapshot_done.record(side)
+            # 2. gather (after the downcast: half the bytes on the wire)
+            full: dict[str, Tensor] = {}
+            for k, v in snap.items():
+                full[k] = v.full_tensor() if isinstance(v, DTensor) else v
+            for fn in self._subscribers:
+                fn(full, step)
+            # 3. copy-out on rank 0
+            host: dict[str, Tensor] = {}
+            copied = None
+            if self._is_master:
+                for k, v in full.items():
+                    if v.device.type == "cuda":
+                        buf = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
+                        buf.copy_(v, non_blocking=True)
+                        host[k] = buf
+                    else:
+                        host[k] = v
+                if side is not None:
+                    copied = torch.cuda.Event()
+                    copied.record(side)
+        # 4. write on a host thread
+        if self._is_master:
+            config = getattr(model, "config", None) if model is not None else None
+            gen_config = getattr(model, "generation_config", None) if model is not None else None
+
+            def write() -> None:
+                try:
+                    if copied is not None:
+                        copied.synchronize()
+                    step_path = get_step_path(self.weights_dir, step)
+                    step_path.mkdir(parents=True, exist_ok=True)
+                    tmp = pending.path.with_suffix(".tmp")
+                    torch.save(host, tmp)
+                    tmp.rename(pending.path)  # existence of the .bin means the file is complete
+                    if config is not None and hasattr(config, "save_pretrained"):
+                        config.save_pretrained(step_path)
+                    if gen_config is not None and hasattr(gen_config, "save_pretrained"):
+                        gen_config.save_pretrained(step_path)
+                    if tokenizer is not None:
+                        tokenizer.save_pretrained(step_path)
+                except BaseException as exc:  # surfaced by wait()
+                    pending.error = exc
+
+            pending._thread = threading.Thread(target=write, name=f"weight-publication-{step}")
+            pending._thread.start()
+        self._pending = [p for p in self._pending if p._thread is not None and p._thread.is_alive()] + [pending]
+        return pending
+
+    def guard_parameters(self) -> None:
+        """Make the compute stream wait until every snapshot in flight has read the parameters.
+        Call before an in-place parameter update (the optimizer step)."""
+        if self.device is None or self.device.type != "cuda":
+            return
+        for p in self._pending:
+            if p.snapshot_done is not None:
+                torch.cuda.current_stream(self.device).wait_event(p.snapshot_done)
+
+    def wait_all(self) -> None:
+        for p in list(self._pending):
+            p.wait()
+
+    # ------------------------------------------------------------------ clean-up
+
+    def keep_step(self, step: int) -> bool:
+        """Whether `weights/step_<step>` must stay: evaluation steps (`step % interval == 0`) and the
+        `async_level + 1` steps leading up to a full checkpoint, which the logprob models of a resumed run
+        need (src/prime_rl/trainer/weights.py:215-223)."""
+        keep_for_eval = bool(self.interval) and step % self.interval == 0
+        keep_for_ckpt = bool(self.ckpt_interval) and (
+            (self.ckpt_interval - (step % self.ckpt_interval)) % self.ckpt_interval <= self.async_level
+        )
+        return keep_for_eval or keep_for_ckpt
+
+    def maybe_clean(self, step: int) -> Path | None:
+        """Consider deleting the directory of `async_level + 1` steps ago
+        (src/prime_rl/trainer/weights.py:211-228).  Returns the path removed, if any."""
+        old = max(step - (self.async_level + 1), 0)
+        if self.keep_step(old):
+            return None
+        path = get_step_path(self.weights_dir, old)
+        shutil.rmtree(path, ignore_errors=True)
+        return path

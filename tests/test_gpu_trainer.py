@@ -93,3 +93,81 @@ def test_bf16_model_step_runs_and_learns_direction():
     assert after.stats["loss/mean"] < before.stats["loss/mean"]
     assert set(k.split("/")[0] for k in before.stats) >= {"probs", "old_probs", "entropy", "loss", "importance_ratio",
                                                          "clipped_importance_ratio", "is_clipped"}
+
+
+def test_recompute_logprobs_matches_reference_chain():
+    """src/prime_rl/trainer/rl/train.py:236-245 with the oracle on the CPU copy of the model."""
+    cfg = tiny_config()
+    cpu_model = T.get_model(cfg, "cpu", torch.float32, seed=8)
+    gpu_model = copy.deepcopy(cpu_model).to(DEV)
+    gen = torch.Generator().manual_seed(9)
+    mbs = rows(gen, 2, [16, 24], cfg.vocab_size)
+    want_lp, want_err = [], []
+    with torch.no_grad():
+        for mb in mbs:
+            logits = T.forward(cpu_model, mb["input_ids"], mb["position_ids"]).float().contiguous()
+            lp = O.selective_log_softmax(O.shift_logits(logits) / mb["temperature"], mb["input_ids"])
+            want_lp.append(lp)
+            want_err.append(torch.exp(lp - mb["logprobs"]))
+    errs = T.recompute_logprobs(gpu_model, mbs, DEV)
+    for mb, lp, err, got in zip(mbs, want_lp, want_err, errs):
+        assert mb["logprobs"].device.type == "cpu"
+        assert torch.allclose(mb["logprobs"], lp, atol=1e-4, rtol=1e-4)
+        assert torch.allclose(got.cpu(), err, atol=1e-4, rtol=1e-3)
+
+
+def _single_rank_env(monkeypatch, port):
+    from prime_rl_cse_amd.world import reset_world
+
+    for k, v in dict(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                     LOCAL_WORLD_SIZE="1").items():
+        monkeypatch.setenv(k, v)
+    reset_world()
+
+
+def test_trainer_entry_point_on_fake_data(tmp_path, monkeypatch):
+    """The counterpart of the reference's `trainer @ configs/debug/rl/train.toml` smoke run
+    (tests/integration/test_trainer.py:10-19): bench mode, fake data, weights published per step."""
+    from prime_rl_cse_amd.settings import RLTrainerConfig, parse_argv
+    from prime_rl_cse_amd.train import train
+
+    _single_rank_env(monkeypatch, 29761)
+    toml = tmp_path / "train.toml"
+    toml.write_text("max_steps = 5\nasync_level = 5\n\n[data.fake]\nbatch_size = 8\nmicro_batch_size = 2\nseq_len = 64\n")
+    cfg = parse_argv(RLTrainerConfig, ["@", str(toml), "--bench", "--model.debug.num-layers", "2", "--output-dir",
+                                       str(tmp_path / "out"), "--recompute-logprobs"], use_env=False)
+    history = train(cfg)
+    assert len(history) == 4 and all(h["time/step"] > 0 for h in history)  # bench: 1 warm-up + 3 measured steps
+    assert {"loss/mean", "entropy/mean", "importance_ratio/mean", "recomputed_logprob_error/mean", "optim/grad_norm",
+            "perf/throughput"} <= set(history[-1])
+    for step in (1, 2, 3, 4):
+        assert (tmp_path / "out" / "weights" / f"step_{step}" / "pytorch_model.bin").exists()
+    assert not list((tmp_path / "out").rglob("*.tmp"))
+    state = torch.load(tmp_path / "out" / "weights" / "step_4" / "pytorch_model.bin", weights_only=True)
+    assert state["model.embed_tokens.weight"].dtype == torch.bfloat16
+    assert state["model.embed_tokens.weight"].shape == (151936, 1024)
+
+
+def test_trainer_entry_point_on_rollout_files(tmp_path, monkeypatch):
+    """Fed by `rollouts/step_N/rank_0.pt` files as the orchestrator writes them
+    (model: tests/integration/test_trainer_path.py:18-82 of the reference)."""
+    from prime_rl_cse_amd.settings import RLTrainerConfig
+    from prime_rl_cse_amd.train import train
+
+    _single_rank_env(monkeypatch, 29762)
+    gen = torch.Generator().manual_seed(3)
+    for step in range(2):
+        rollouts = []
+        for pid in range(6):
+            p, c = int(torch.randint(4, 20, (1,), generator=gen)), int(torch.randint(4, 40, (1,), generator=gen))
+            rollouts.append(prl.Rollout(pid, torch.randint(0, 1000, (p,), generator=gen).tolist(), [0] * p,
+                                        torch.randint(0, 1000, (c,), generator=gen).tolist(), [1] * c,
+                                        (-6 - torch.rand(c, generator=gen)).tolist(), False, 1.0,
+                                        float(torch.randn(1, generator=gen))))
+        prl.save_rollout_batches(prl.prepare_batch(rollouts, 1.0, None, 6, 2, 64, 1), tmp_path, step)
+    cfg = RLTrainerConfig(max_steps=2, output_dir=tmp_path, model={"debug": {"num_layers": 1}},
+                          loss={"ratio_type": "sequence"})
+    history = train(cfg)
+    assert len(history) == 2 and history[0]["optim/grad_norm"] > 0
+    assert "importance_ratio/mean" not in history[0]  # per-sample ratios are not logged per token
+    assert (tmp_path / "weights" / "step_2" / "pytorch_model.bin").exists()

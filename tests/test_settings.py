@@ -1,0 +1,108 @@
+"""The trainer's configuration surface: TOML recipes, `@ file` syntax, dotted CLI overrides, inheritance,
+environment, validators (model: tests/unit/test_config.py:51-112 of the reference, which loads every recipe)."""
+
+from pathlib import Path
+
+import pytest
+
+from prime_rl_cse_amd.settings import RLTrainerConfig, load_config, parse_argv
+
+REFERENCE_CONFIGS = Path("/root/reference")
+
+
+def write(tmp_path, name, text):
+    p = tmp_path / name
+    p.write_text(text)
+    return p
+
+
+def test_defaults_match_reference():
+    c = RLTrainerConfig()
+    assert c.model.name == "Qwen/Qwen3-0.6B" and c.model.attn == "flash_attention_2" and c.model.impl == "hf"
+    assert c.model.optimization_dtype == "float32" and c.model.reduce_dtype == "float32"
+    assert (c.optim.type, c.optim.lr, c.optim.weight_decay, c.optim.max_norm) == ("adamw", 1e-6, 0.01, 1.0)
+    assert (c.optim.betas1, c.optim.betas2) == (0.9, 0.999) and c.scheduler.type == "constant"
+    assert (c.loss.ratio_type, c.loss.clip_ratio) == ("token", 8.0)
+    assert c.async_level == 2 and c.max_steps is None and c.ckpt is None and c.weights.save_async
+    assert c.output_dir == Path("outputs") and c.dist_timeout_seconds == 600 and not c.recompute_logprobs
+
+
+def test_recipe_shaped_toml_with_at_syntax(tmp_path):
+    f = write(tmp_path, "train.toml", """
+max_steps = 20
+async_level = 5
+
+[model]
+name = "PrimeIntellect/Qwen3-0.6B-Reverse-Text-SFT"
+
+[optim]
+lr = 3e-6
+
+[data.fake]
+batch_size = 16
+micro_batch_size = 1
+seq_len = 128
+
+[loss]
+ratio_type = "sequence"
+clip_ratio = 4.0
+""")
+    c = parse_argv(RLTrainerConfig, ["@", str(f), "--optim.max-norm", "0.5", "--model.attn=sdpa", "--recompute_logprobs"],
+                   use_env=False)
+    assert c.max_steps == 20 and c.async_level == 5 and c.model.name.endswith("Reverse-Text-SFT")
+    assert c.optim.lr == 3e-6 and c.optim.max_norm == 0.5 and c.model.attn == "sdpa" and c.recompute_logprobs
+    assert c.data.fake.batch_size == 16 and c.loss.ratio_type == "sequence" and c.loss.clip_ratio == 4.0
+    # `@file` glued form and a file loaded under a key
+    g = write(tmp_path, "optim.toml", 'type = "sgd"\nlr = 0.1\n')
+    c = parse_argv(RLTrainerConfig, [f"@{f}", "--optim", "@", str(g)], use_env=False)
+    assert c.optim.type == "sgd" and c.optim.lr == 0.1 and c.optim.nesterov and c.max_steps == 20
+
+
+def test_inheritance_and_precedence(tmp_path, monkeypatch):
+    write(tmp_path, "base.toml", 'max_steps = 7\nasync_level = 1\n[optim]\nlr = 1e-5\n')
+    main = write(tmp_path, "main.toml", 'toml_files = ["base.toml"]\nmax_steps = 3\n[optim]\nweight_decay = 0.1\n')
+    c = load_config(RLTrainerConfig, main)
+    # the files a file names take precedence over it; untouched keys survive the merge
+    assert c.max_steps == 7 and c.async_level == 1 and c.optim.lr == 1e-5 and c.optim.weight_decay == 0.1
+    monkeypatch.setenv("PRIME_ASYNC_LEVEL", "9")
+    monkeypatch.setenv("PRIME_OPTIM__LR", "0.5")
+    monkeypatch.setenv("PRIME_UNRELATED_THING", "x")
+    c = parse_argv(RLTrainerConfig, ["@", str(main), "--max-steps", "11"])
+    assert c.max_steps == 11 and c.async_level == 1 and c.optim.lr == 1e-5  # CLI > TOML > environment
+    c = parse_argv(RLTrainerConfig, [])
+    assert c.async_level == 9 and c.optim.lr == 0.5
+
+
+def test_booleans_none_strings_and_optional_sections(tmp_path):
+    c = parse_argv(RLTrainerConfig, ["--bench"], use_env=False)
+    assert c.bench and c.max_steps == 4 and c.data.fake is not None and c.ckpt is None
+    c = parse_argv(RLTrainerConfig, ["--ckpt", "--ckpt.interval", "5", "--weights.no-save-async"], use_env=False)
+    assert c.ckpt.interval == 5 and c.weights.save_async is False
+    f = write(tmp_path, "n.toml", '[data]\nfake = "None"\n[wandb]\nproject = "x"\n')
+    c = load_config(RLTrainerConfig, f)
+    assert c.data.fake is None and c.wandb.project == "x" and c.wandb.log_extras.samples is False
+
+
+def test_validation_errors(tmp_path):
+    with pytest.raises(Exception):
+        parse_argv(RLTrainerConfig, ["--not-a-field", "1"], use_env=False)
+    with pytest.raises(Exception):
+        parse_argv(RLTrainerConfig, ["--optim.type", "adagrad"], use_env=False)
+    with pytest.raises(Exception, match="max_steps"):
+        RLTrainerConfig(trace_path="t")
+    with pytest.raises(Exception, match="massive"):
+        RLTrainerConfig(trace_path="t", max_steps=10)
+    with pytest.raises(Exception, match="meta"):
+        RLTrainerConfig(model={"debug": {"random_init": True}})
+    with pytest.raises(FileNotFoundError):
+        parse_argv(RLTrainerConfig, ["@", str(tmp_path / "missing.toml")], use_env=False)
+
+
+@pytest.mark.skipif(not REFERENCE_CONFIGS.exists(), reason="the reference's recipes exist in the build container only")
+def test_every_reference_rl_trainer_recipe_loads():
+    files = sorted(REFERENCE_CONFIGS.glob("configs/**/rl/train.toml")) + sorted(
+        REFERENCE_CONFIGS.glob("examples/**/rl/train.toml"))
+    assert len(files) >= 15
+    for f in files:
+        c = load_config(RLTrainerConfig, f)
+        assert c.model.name

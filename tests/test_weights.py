@@ -1,0 +1,130 @@
+"""Weight publication: file layout and atomic rename of the reference, the keep / clean rule,
+the gather over ranks (gloo, world size 2) and, on the GPU, the side-stream snapshot."""
+
+import os
+from pathlib import Path
+
+import pytest
+import torch
+from torch import nn
+
+from prime_rl_cse_amd.weights import (
+    WeightPublisher, get_weight_ckpt_model_path, get_weights_dir, wait_for_weight_checkpoint,
+)
+from prime_rl_cse_amd.world import reset_world
+
+
+class Tiny(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(6, 5)
+        self.b = nn.Embedding(7, 3)
+        self.register_buffer("steps", torch.tensor([3], dtype=torch.int64))
+
+
+def test_publish_writes_reference_layout(tmp_path):
+    reset_world()
+    torch.manual_seed(0)
+    model = Tiny()
+    pub = WeightPublisher(tmp_path, async_level=1)
+    pending = pub.publish(model, step=4)
+    path = pending.wait(timeout=30)
+    assert path == tmp_path / "weights" / "step_4" / "pytorch_model.bin" == get_weight_ckpt_model_path(
+        get_weights_dir(tmp_path), 4)
+    assert path.exists() and not list(tmp_path.rglob("*.tmp"))
+    wait_for_weight_checkpoint(get_weights_dir(tmp_path), 4, interval=0.01, timeout=1)
+    state = torch.load(path, weights_only=True)
+    assert set(state) == set(model.state_dict())
+    for k, v in model.state_dict().items():
+        if v.is_floating_point():
+            assert state[k].dtype == torch.bfloat16 and torch.equal(state[k], v.to(torch.bfloat16))
+        else:
+            assert torch.equal(state[k], v)
+
+
+def test_keep_and_clean_rule(tmp_path):
+    # src/prime_rl/trainer/weights.py:211-228: consider step - (async_level + 1); keep evaluation steps and the
+    # async_level + 1 steps that lead up to a full checkpoint
+    reset_world()
+    pub = WeightPublisher(tmp_path, interval=10, ckpt_interval=8, async_level=2)
+    assert pub.keep_step(0) and pub.keep_step(10) and pub.keep_step(20)  # evaluation steps
+    assert pub.keep_step(6) and pub.keep_step(7) and pub.keep_step(8) and pub.keep_step(14)  # 8-2 .. 8, 16-2
+    assert not pub.keep_step(5) and not pub.keep_step(9) and not pub.keep_step(11)
+    for s in (3, 5, 6):
+        (tmp_path / "weights" / f"step_{s}").mkdir(parents=True)
+    assert pub.maybe_clean(8) == tmp_path / "weights" / "step_5" and not (tmp_path / "weights" / "step_5").exists()
+    assert pub.maybe_clean(9) is None and (tmp_path / "weights" / "step_6").exists()  # kept for the checkpoint at 8
+    no_rules = WeightPublisher(tmp_path, async_level=2)
+    assert no_rules.maybe_clean(6) == tmp_path / "weights" / "step_3"
+
+
+def _rank(rank, world, port, root, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from torch.distributed.device_mesh import init_device_mesh
+    from torch.distributed.tensor import Shard, distribute_tensor
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        reset_world()
+        mesh = init_device_mesh("cpu", (world,))
+        gen = torch.Generator().manual_seed(1)
+        full = {"w_even": torch.randn(8, 3, generator=gen), "w_odd": torch.randn(5, 4, generator=gen),
+                "w_one_row": torch.randn(1, 6, generator=gen), "plain": torch.arange(4.0)}
+        state = {k: (distribute_tensor(v, mesh, [Shard(0)]) if k != "plain" else v) for k, v in full.items()}
+        pub = WeightPublisher(Path(root), async_level=1)
+        pending = pub.publish(None, step=2, state_dict=state)
+        pending.wait(timeout=60)
+        dist.barrier()
+        q.put((rank, {k: v.tolist() for k, v in full.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_gather_sharded_weights_over_gloo(tmp_path):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank, args=(r, 2, 29751, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    state = torch.load(get_weight_ckpt_model_path(get_weights_dir(tmp_path), 2), weights_only=True)
+    want = {k: torch.tensor(v) for k, v in res[0][1].items()}
+    assert set(state) == set(want)
+    for k, v in want.items():
+        assert state[k].shape == v.shape and torch.equal(state[k], v.to(torch.bfloat16)), k
+
+
+@pytest.mark.gpu
+def test_side_stream_snapshot_is_not_disturbed_by_the_next_update(tmp_path):
+    """The file holds the weights as they were at publish(); an optimizer-like in-place update issued right
+    afterwards (behind guard_parameters) must not leak into it."""
+    reset_world()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    model = nn.Sequential(nn.Linear(1024, 1024), nn.Linear(1024, 1024)).to(dev)
+    before = {k: v.detach().to(torch.bfloat16).cpu() for k, v in model.state_dict().items()}
+    pub = WeightPublisher(tmp_path, async_level=1, device=dev)
+    seen = {}
+    pub.add_device_subscriber(lambda state, step: seen.update(step=step, keys=set(state), dev=next(iter(state.values())).device))
+    pending = pub.publish(model, step=1)
+    pub.guard_parameters()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(1.0)
+    path = pending.wait(timeout=60)
+    state = torch.load(path, weights_only=True)
+    for k, v in before.items():
+        assert torch.equal(state[k], v), k
+    assert seen["step"] == 1 and seen["keys"] == set(before) and seen["dev"].type == "cuda"
+    # a second publication sees the update
+    path2 = pub.publish(model, step=2).wait(timeout=60)
+    state2 = torch.load(path2, weights_only=True)
+    assert torch.equal(state2["0.weight"], (model.state_dict()["0.weight"]).to(torch.bfloat16).cpu())
+    assert not torch.equal(state2["0.weight"], state["0.weight"])
