@@ -10,6 +10,7 @@ from typing import Any
 # Dense bf16 peak FLOP/s by a substring of the device name.  MI355X: 2.5 PFLOP/s dense
 # (the 5 PFLOP/s headline figure assumes 2:1 structured sparsity).
 PEAK_BF16_FLOPS = {
+    "gfx950": 2.5e15,  # some driver stacks report MI355X only as "AMD Radeon Graphics"; the architecture string is reliable
     "MI355": 2.5e15,
     "MI350": 2.3e15,
     "MI325": 1.307e15,
@@ -22,7 +23,15 @@ PEAK_BF16_FLOPS = {
     "B200": 2.25e15,
 }
 # Peak HBM bandwidth in bytes/s by a substring of the device name (MI355X: 8 TB/s HBM3E).
-PEAK_HBM_BYTES = {"MI355": 8.0e12, "MI350": 8.0e12, "MI325": 6.0e12, "MI300X": 5.3e12}
+PEAK_HBM_BYTES = {"gfx950": 8.0e12, "MI355": 8.0e12, "MI350": 8.0e12, "MI325": 6.0e12, "MI300X": 5.3e12}
+
+
+def describe_device(device) -> str:
+    """Marketing name plus architecture string of a torch device, the text the peak tables are matched against."""
+    import torch
+
+    props = torch.cuda.get_device_properties(device)
+    return f"{props.name} {getattr(props, 'gcnArchName', '')}".strip()
 
 
 def peak_bf16_flops(device_name: str) -> float:

@@ -22,7 +22,7 @@ from . import trainer as T
 from .data import DataLoader, FakeDataLoader
 from .optim import setup_optimizer, setup_scheduler
 from .settings import RLTrainerConfig, parse_argv
-from .weights import WeightPublisher, get_weight_ckpt_model_path, get_weights_dir
+from .weights import WeightPublisher
 from .world import get_world
 
 DTYPES = {"bfloat16": torch.bfloat16, "float32": torch.float32}
@@ -84,6 +84,15 @@ def train(config: RLTrainerConfig) -> list[dict[str, float]]:
     if config.model.cp > 1:
         raise ValueError("CP is not supported for RL. No reason it shouldn't, we just didn't test it.")
     mesh = T.init_distributed(device)
+    try:
+        return _train(config, world, device, mesh)
+    finally:
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def _train(config: RLTrainerConfig, world: Any, device: torch.device, mesh: Any) -> list[dict[str, float]]:
     log(f"Starting RL trainer on {world}")
     model, model_cfg = build_model(config, device, mesh)
     optimizer = setup_optimizer(config.optim, model)
@@ -96,7 +105,7 @@ def train(config: RLTrainerConfig) -> list[dict[str, float]]:
         logprob_model, _ = build_model(config, device, mesh, dtype=torch.bfloat16)
         logprob_model.requires_grad_(False)
     snapshots: dict[int, dict[str, torch.Tensor]] = {}
-    device_name = torch.cuda.get_device_name(device)
+    device_name = perf.describe_device(device)
     counter = None
     history: list[dict[str, float]] = []
     step = 0
@@ -151,9 +160,6 @@ def train(config: RLTrainerConfig) -> list[dict[str, float]]:
     publisher.wait_all()
     if config.bench and len(history) > 1:
         print_benchmark(history)
-    if dist.is_initialized():
-        dist.barrier()
-        dist.destroy_process_group()
     return history
 
 

@@ -162,7 +162,7 @@ def test_trainer_entry_point_on_rollout_files(tmp_path, monkeypatch):
             p, c = int(torch.randint(4, 20, (1,), generator=gen)), int(torch.randint(4, 40, (1,), generator=gen))
             rollouts.append(prl.Rollout(pid, torch.randint(0, 1000, (p,), generator=gen).tolist(), [0] * p,
                                         torch.randint(0, 1000, (c,), generator=gen).tolist(), [1] * c,
-                                        (-6 - torch.rand(c, generator=gen)).tolist(), False, 1.0,
+                                        (-11.9 + 0.05 * torch.randn(c, generator=gen)).tolist(), False, 1.0,  # near ln V of a random model
                                         float(torch.randn(1, generator=gen))))
         prl.save_rollout_batches(prl.prepare_batch(rollouts, 1.0, None, 6, 2, 64, 1), tmp_path, step)
     cfg = RLTrainerConfig(max_steps=2, output_dir=tmp_path, model={"debug": {"num_layers": 1}},

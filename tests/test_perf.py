@@ -18,6 +18,7 @@ def test_qwen3_0_6b_known_answers():
 
 def test_mi355x_peaks_and_unknown_devices():
     assert perf.peak_bf16_flops("AMD Instinct MI355X") == 2.5e15
+    assert perf.peak_bf16_flops("AMD Radeon Graphics gfx950:sramecc+:xnack-") == 2.5e15
     assert perf.peak_hbm_bytes("AMD Instinct MI355X") == 8.0e12
     assert perf.peak_bf16_flops("NVIDIA H100 80GB HBM3") == 989e12
     with pytest.raises(KeyError):
