@@ -43,34 +43,37 @@ def wait_for_path(path: Path, interval: float = 1.0, timeout: float | None = Non
         waited += interval
 
 
+def synthetic_row(micro_batch_size: int, seq_len: int, generator: torch.Generator) -> MicroBatch:
+    """One packed row of `micro_batch_size` full-length samples with random content: token ids below 100,
+    standard-normal advantages and sampler log-probabilities, every token in the loss, temperature 1
+    (the distribution of src/prime_rl/trainer/rl/data.py:39-54)."""
+    t = micro_batch_size * seq_len
+    row: MicroBatch = {"temperature": 1.0}
+    row["input_ids"] = torch.randint(0, 100, (1, t), generator=generator)
+    row["position_ids"] = torch.arange(seq_len).repeat(micro_batch_size).unsqueeze(0)
+    for key in ("advantages", "logprobs"):
+        row[key] = torch.randn(1, t, generator=generator)
+    row["loss_mask"] = torch.ones(1, t, dtype=torch.bool)
+    return row
+
+
 class FakeDataLoader:
-    """Random micro-batches of fixed shape (src/prime_rl/trainer/rl/data.py:26-54).
-    Unlike the reference the generator is seeded (1234 + rank) so runs repeat."""
+    """Synthetic batches of fixed shape for debugging and benchmarks; each rank gets
+    batch_size / micro_batch_size / world_size rows per step (src/prime_rl/trainer/rl/data.py:26-37).
+    Unlike the reference the generator is seeded (1234 + rank), so runs repeat."""
 
     def __init__(self, config: FakeDataLoaderConfig, seed: int | None = None):
-        self.batch_size = config.batch_size
-        self.micro_batch_size = config.micro_batch_size
-        self.num_micro_batches = self.batch_size // self.micro_batch_size // get_world().world_size
-        self.seq_len = config.seq_len
-        self.generator = torch.Generator().manual_seed(1234 + get_world().rank if seed is None else seed)
+        world = get_world()
+        self.config = config
+        self.num_micro_batches = config.batch_size // config.micro_batch_size // world.world_size
+        self.generator = torch.Generator().manual_seed(1234 + world.rank if seed is None else seed)
 
     def wait_for_batch(self) -> None:
-        return
+        """Nothing to wait for."""
 
     def get_batch(self) -> list[MicroBatch]:
-        return [self._get_micro_batch() for _ in range(self.num_micro_batches)]
-
-    def _get_micro_batch(self) -> MicroBatch:
-        t = self.micro_batch_size * self.seq_len
-        g = self.generator
-        return {
-            "input_ids": torch.randint(0, 100, (1, t), generator=g),
-            "position_ids": torch.cat([torch.arange(self.seq_len)] * self.micro_batch_size).unsqueeze(0),
-            "advantages": torch.randn(t, generator=g).unsqueeze(0),
-            "logprobs": torch.randn(t, generator=g).unsqueeze(0),
-            "temperature": 1.0,
-            "loss_mask": torch.ones(t, dtype=torch.bool).unsqueeze(0),
-        }
+        c = self.config
+        return [synthetic_row(c.micro_batch_size, c.seq_len, self.generator) for _ in range(self.num_micro_batches)]
 
 
 class DataLoader:
