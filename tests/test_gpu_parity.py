@@ -599,3 +599,24 @@ def test_skip_masked_changes_nothing_that_is_used():
         assert torch.equal(a0["entropy"][0][m], a1["entropy"][0][m])
         assert not a1["logprobs"][0][~m].any() and not a1["entropy"][0][~m].any()
         assert a0["logprobs"][0][~m].abs().min() > 0
+
+
+@pytest.mark.parametrize("rtype", ["token", "sequence"])
+def test_long_row_takes_the_multi_kernel_bookkeeping_path(rtype):
+    """Rows above 16384 tokens use one kernel per step of the bookkeeping instead of the fused one."""
+    gen = torch.Generator().manual_seed(51)
+    lengths = torch.randint(2, 400, (120,), generator=gen).tolist()
+    cfg = prl.LossConfig(ratio_type=rtype, ratio_length_norm=(rtype == "sequence"), clip_ratio=1.2)
+    want, loss, aux, grad = oracle_and_hip(gen, lengths, 5, 64, 1.0, torch.float32, cfg)
+    t = sum(lengths) + 5
+    assert t > 16384
+    close(aux["logprobs"], want["logprobs"])
+    close(loss, want["loss"])
+    k = len(want["lengths"]) if rtype == "sequence" else t
+    close(aux["importance_ratio"][:k], want["importance_ratio"])
+    close(aux["clipped_importance_ratio"][:k], want["clipped_importance_ratio"])
+    close(aux["is_clipped"][:k], want["is_clipped"])
+    grad_close(grad, want["dlogits"])
+    n = int(aux["n_seg"].item())
+    starts = aux["seg_start"][: n + 1].cpu()
+    assert (starts[1:] - starts[:-1]).tolist() == want["lengths"]
