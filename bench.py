@@ -262,10 +262,17 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with torch.distributed.run, one rank per GPU")
+    # one rank per GPU over RCCL.  PRL_BENCH_BACKEND=gloo is a rehearsal aid for boxes with fewer GPUs than
+    # ranks: ranks then share devices round-robin and exchange through host memory.
+    backend = os.environ.get("PRL_BENCH_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import prime_rl_cse_amd as prl
     from prime_rl_cse_amd import _capi, perf  # noqa: F401
@@ -327,7 +334,7 @@ def main() -> None:
     torch.cuda.synchronize()
     _capi.set_timer(None)
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
