@@ -8,8 +8,11 @@ micro-batch: 8 packed rows of T = 2048 tokens, vocabulary V = 151936).  Per
 packed row the path takes the model's logits, already resident in HBM, to the
 loss, the logged tensors and the gradient with respect to the logits:
 
-    sample boundaries -> per-token logprob + entropy (one pass over the logits)
-    -> ratio-clip loss + dL/dlogprob -> dL/dlogits (second pass) -> statistics
+    per-token logprob + entropy + dL/dlogits in ONE pass over the logits (bf16; a row is held in a
+    compute unit's registers between its read and the write of its gradient)
+    -> sample boundaries, ratio-clip loss and logged tensors -> statistics
+
+(fp32 logits, --logits-dtype f32, take two passes: logprob + entropy, then dL/dlogits.)
 
 Every rank runs the same amount of work on its own rollouts (data parallel, no
 collective on the data path); the reported value is the job total.  Rank 0
@@ -307,7 +310,7 @@ def main() -> None:
 
     # inside the timed region only the dominant kernel carries events (every event pair costs a few
     # microseconds of queue time); the other kernels are timed in a short untimed pass afterwards
-    timer = _capi.KernelTimer(only={"prl_logprob_bwd"})
+    timer = _capi.KernelTimer(only={"prl_logprob_bwd", "prl_policy_rows_fwd_bwd"})
     _capi.set_timer(timer)
     if world > 1:
         dist.barrier()
@@ -344,14 +347,21 @@ def main() -> None:
     if rank == 0:
         t = MICRO_BATCH * SEQ_LEN
         k = side.summary()
-        bwd, fwd = timer.summary()["prl_logprob_bwd"], k["prl_policy_forward"]
-        # algorithmic bytes per launch: the backward reads V logits for every row that
-        # carries a gradient (all but the one dropped by the shift) and writes V
-        # gradient elements for every row; the forward reads V logits for T-1 rows
+        timed = timer.summary()
+        single_pass = "prl_policy_rows_fwd_bwd" in timed
+        # algorithmic bytes per launch: V logits read for every row that predicts a token (all but the
+        # one dropped by the shift) and V gradient elements written for every row; the single-pass kernel
+        # adds the 12 bytes of logprob, entropy and lse per token, the two-pass forward reads the rows once more
         bwd_bytes = (t - 1) * VOCAB * es + t * VOCAB * es
         fwd_bytes = (t - 1) * VOCAB * es + 12 * t
-        achieved = bwd_bytes / (bwd["mean_ms"] * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic("k_logprob_bwd", args.logits_dtype)
+        if single_pass:
+            dom_name, dom_call, dom = "k_policy_rows", "prl_policy_rows_fwd_bwd", timed["prl_policy_rows_fwd_bwd"]
+            dom_bytes = bwd_bytes + 12 * t
+        else:
+            dom_name, dom_call, dom = "k_logprob_bwd", "prl_logprob_bwd", timed["prl_logprob_bwd"]
+            dom_bytes = bwd_bytes
+        achieved = dom_bytes / (dom["mean_ms"] * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(dom_name, args.logits_dtype)
         line = {
             "metric": "policy_update_samples_per_sec",
             "value": value,
@@ -378,21 +388,25 @@ def main() -> None:
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_logprob_bwd",
+                "kernel": dom_name,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
-                "bytes_per_launch": bwd_bytes,
-                "mean_ms": bwd["mean_ms"],
-                "launches": bwd["launches"],
+                "bytes_per_launch": dom_bytes,
+                "mean_ms": dom["mean_ms"],
+                "launches": dom["launches"],
             },
             "kernels": {
-                # one library call: k_logprob_fwd, then k_segments and k_grpo_loss (microseconds each)
-                "prl_policy_forward": {"mean_ms": fwd["mean_ms"], "GBps": fwd_bytes / (fwd["mean_ms"] * 1e-3) / 1e9},
-                "k_logprob_bwd": {"mean_ms": bwd["mean_ms"], "GBps": achieved},
+                dom_call: {"mean_ms": dom["mean_ms"], "GBps": achieved},
+                # two-pass path only: one library call holding k_logprob_fwd and the bookkeeping kernel
+                **({"prl_policy_forward": {"mean_ms": k["prl_policy_forward"]["mean_ms"],
+                                           "GBps": fwd_bytes / (k["prl_policy_forward"]["mean_ms"] * 1e-3) / 1e9}}
+                   if "prl_policy_forward" in k else {}),
+                **({name: {"mean_ms": k[name]["mean_ms"]} for name in ("prl_policy_tail", "prl_scale_rows_if_not_one")
+                    if name in k}),
                 **({"prl_stats(all keys)": {"mean_ms": k["prl_stats"]["mean_ms"]}} if "prl_stats" in k else {}),
             },
         }

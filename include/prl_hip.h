@@ -160,6 +160,57 @@ int prl_policy_forward(const void* logits, int logits_dtype, int64_t T, int64_t 
                        int64_t* seg_start, int32_t* n_seg, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * Everything of prl_policy_forward that comes after the log-probabilities:
+ * sample boundaries from the position ids (src/prime_rl/trainer/utils.py:36-69),
+ * the ratio-clip loss and its three logged tensors
+ * (src/prime_rl/trainer/rl/loss.py:61-124) and g = dL/dlogprob.  One launch of
+ * one workgroup for rows of up to 16384 tokens.  Buffer sizes as for
+ * prl_policy_forward.
+ */
+int prl_policy_tail(const int64_t* pos, const float* logprob, const float* old, const float* adv,
+                    const uint8_t* mask, int64_t T, int ratio_type, int length_norm, float clip_ratio,
+                    float loss_scale, float* loss, float* ratio, float* clipped, float* is_clipped, float* g,
+                    float* seg_loss, int32_t* seg_id, int64_t* seg_start, int32_t* n_seg, void* stream);
+
+/*
+ * Token-mode forward AND backward of one packed row in a single pass over the
+ * logits.  Each workgroup keeps one bf16 row of logits in registers, so the
+ * row is read from memory once and the gradient is written once: per token V
+ * logits in, V gradient elements out, and no second read for the backward.
+ * Replaces, for ratio_type "token", src/prime_rl/trainer/rl/train.py:285-310
+ * from the shift to `loss.backward()` reaching the logits: logprob, entropy
+ * and lse as prl_logprob_entropy_fwd with shift = 1 gives them, and
+ *   dlogits[t-1, :] = g[t] / temperature * (onehot(ids[t]) - softmax(logits[t-1] / temperature)),
+ *   g[t] = mask[t] * [ratio <= clip] * (-adv[t] * ratio / max(loss_scale, 1)),  ratio = exp(logprob[t] - old[t])
+ * (src/prime_rl/trainer/rl/loss.py:90, 98-104 differentiated), i.e. the
+ * gradient of the scaled loss for an incoming gradient of 1; dlogits[T-1, :] = 0.
+ * The scalar loss and the logged ratio tensors come from prl_policy_tail run
+ * on the logprob this call wrote.  skip_masked as in prl_policy_forward.
+ *
+ * Limits (prl_policy_rows_supported returns 1 when they hold): bf16 logits and
+ * gradient, V a multiple of 8 and at most 155648, row strides multiples of 8,
+ * both base pointers 16-byte aligned.  Sequence-mode losses and fp32 logits
+ * use prl_policy_forward + prl_logprob_bwd.
+ */
+int prl_policy_rows_supported(int logits_dtype, int64_t T, int64_t V, int64_t row_stride, int out_dtype,
+                              int64_t out_row_stride);
+int prl_policy_rows_fwd_bwd(const void* logits, int logits_dtype, int64_t T, int64_t V, int64_t row_stride,
+                            const int64_t* ids, const float* adv, const float* old, const uint8_t* mask,
+                            int skip_masked, float temperature, float clip_ratio, float loss_scale, float* logprob,
+                            float* entropy, float* lse, void* dlogits, int out_dtype, int64_t out_row_stride,
+                            void* stream);
+
+/*
+ * x[T, V] *= scale[0] in place, where scale is a device scalar; when it is
+ * exactly 1 the kernel returns without touching x.  Lets the backward of
+ * prl_policy_rows_fwd_bwd honour an incoming loss gradient other than 1
+ * (autograd's grad_output at src/prime_rl/trainer/rl/train.py:310) without a
+ * host synchronisation to look at its value.
+ */
+int prl_scale_rows_if_not_one(void* x, int dtype, int64_t T, int64_t V, int64_t row_stride, const float* scale,
+                              void* stream);
+
+/*
  * Group-relative advantages: B rewards in consecutive groups of G.  Replaces
  * compute_advantages (src/prime_rl/orchestrator/advantage.py:71-103) for the
  * four kinds of its REGISTRY (:63-68).  `lengths` (int64 [B], completion

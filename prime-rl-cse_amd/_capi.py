@@ -56,6 +56,18 @@ SIGNATURES = {
          c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p],
     ),
+    "prl_policy_tail": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_float, c_void_p,
+         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
+    "prl_policy_rows_supported": (c_int, [c_int, c_int64, c_int64, c_int64, c_int, c_int64]),
+    "prl_policy_rows_fwd_bwd": (
+        c_int,
+        [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float,
+         c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p],
+    ),
+    "prl_scale_rows_if_not_one": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "prl_group_advantage": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "prl_stats_workspace_bytes": (c_size_t, [c_int]),
     "prl_stats_layout": (c_int, [c_int, POINTER(c_int64)]),

@@ -145,32 +145,42 @@ __global__ __launch_bounds__(kSmallThreads) void k_policy_small(
 
 }  // namespace prl
 
+extern "C" int prl_policy_tail(const int64_t* pos, const float* logprob, const float* old, const float* adv,
+                               const uint8_t* mask, int64_t T, int ratio_type, int length_norm, float clip_ratio,
+                               float loss_scale, float* loss, float* ratio, float* clipped, float* is_clipped, float* g,
+                               float* seg_loss, int32_t* seg_id, int64_t* seg_start, int32_t* n_seg, void* stream) {
+  prl::clear_error();
+  PRL_REQUIRE(T >= 0, "policy_tail: T must be >= 0");
+  PRL_REQUIRE(ratio_type == PRL_RATIO_TOKEN || ratio_type == PRL_RATIO_SEQUENCE, "policy_tail: bad ratio_type %d",
+              ratio_type);
+  if (T > 0 && T <= prl::kSmallMaxTokens) {
+    PRL_REQUIRE(pos && logprob && adv && old && mask && loss && seg_start && n_seg,
+                "policy_tail: pos, logprob, adv, old, mask, loss, seg_start and n_seg must not be NULL");
+    const float scale = loss_scale > 1.0f ? loss_scale : 1.0f;  // max(loss_scale, 1)
+    hipLaunchKernelGGL(prl::k_policy_small, dim3(1), dim3(prl::kSmallThreads), 0, (hipStream_t)stream, pos, logprob,
+                       old, adv, mask, T, ratio_type, length_norm ? 1 : 0, clip_ratio, scale, loss, ratio, clipped,
+                       is_clipped, g, seg_loss, seg_id, seg_start, n_seg);
+    PRL_CHECK_LAUNCH("policy_tail(small)");
+    return PRL_OK;
+  }
+  int rc = prl_segments_from_position_ids(pos, T, seg_id, seg_start, n_seg, stream);
+  if (rc != PRL_OK) return rc;
+  const int64_t max_seg = T > 0 ? T / 2 + 1 : 0;  // a sample needs two tokens to open
+  return prl_grpo_loss(logprob, old, adv, mask, seg_start, n_seg, max_seg, T, ratio_type, length_norm, clip_ratio,
+                       loss_scale, loss, ratio, clipped, is_clipped, g, seg_loss, stream);
+}
+
 extern "C" int prl_policy_forward(const void* logits, int logits_dtype, int64_t T, int64_t V, int64_t row_stride,
                                   const int64_t* ids, const int64_t* pos, const float* adv, const float* old,
                                   const uint8_t* mask, int skip_masked, float temperature, int ratio_type,
-                                  int length_norm, float clip_ratio, float loss_scale, float* logprob, float* entropy, float* lse,
-                                  float* loss, float* ratio, float* clipped, float* is_clipped, float* g,
+                                  int length_norm, float clip_ratio, float loss_scale, float* logprob, float* entropy,
+                                  float* lse, float* loss, float* ratio, float* clipped, float* is_clipped, float* g,
                                   float* seg_loss, int32_t* seg_id, int64_t* seg_start, int32_t* n_seg,
                                   void* workspace, size_t workspace_bytes, void* stream) {
   PRL_REQUIRE(logprob, "policy_forward: logprob must not be NULL");
   int rc = prl::logprob_fwd_impl(logits, logits_dtype, T, V, row_stride, ids, temperature, 1,
                                  skip_masked ? mask : nullptr, logprob, entropy, lse, workspace, workspace_bytes, stream);
   if (rc != PRL_OK) return rc;
-  if (T > 0 && T <= prl::kSmallMaxTokens) {
-    PRL_REQUIRE(pos && adv && old && mask && loss && seg_start && n_seg,
-                "policy_forward: pos, adv, old, mask, loss, seg_start and n_seg must not be NULL");
-    PRL_REQUIRE(ratio_type == PRL_RATIO_TOKEN || ratio_type == PRL_RATIO_SEQUENCE, "policy_forward: bad ratio_type %d",
-                ratio_type);
-    const float scale = loss_scale > 1.0f ? loss_scale : 1.0f;  // max(loss_scale, 1)
-    hipLaunchKernelGGL(prl::k_policy_small, dim3(1), dim3(prl::kSmallThreads), 0, (hipStream_t)stream, pos, logprob,
-                       old, adv, mask, T, ratio_type, length_norm ? 1 : 0, clip_ratio, scale, loss, ratio, clipped,
-                       is_clipped, g, seg_loss, seg_id, seg_start, n_seg);
-    PRL_CHECK_LAUNCH("policy_forward(small)");
-    return PRL_OK;
-  }
-  rc = prl_segments_from_position_ids(pos, T, seg_id, seg_start, n_seg, stream);
-  if (rc != PRL_OK) return rc;
-  const int64_t max_seg = T > 0 ? T / 2 + 1 : 0;  // a sample needs two tokens to open
-  return prl_grpo_loss(logprob, old, adv, mask, seg_start, n_seg, max_seg, T, ratio_type, length_norm, clip_ratio,
-                       loss_scale, loss, ratio, clipped, is_clipped, g, seg_loss, stream);
+  return prl_policy_tail(pos, logprob, old, adv, mask, T, ratio_type, length_norm, clip_ratio, loss_scale, loss, ratio,
+                         clipped, is_clipped, g, seg_loss, seg_id, seg_start, n_seg, stream);
 }

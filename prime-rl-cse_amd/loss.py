@@ -308,10 +308,20 @@ def _u8(mask: Tensor) -> Tensor:
     return m.contiguous().view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8).contiguous()
 
 
+def _rows_kernel_enabled() -> bool:
+    """The register-resident single-pass kernel is used whenever it applies; PRL_FUSED_ROWS=0 switches it off
+    (for A/B measurements against the two-kernel path)."""
+    import os
+
+    return os.environ.get("PRL_FUSED_ROWS", "1") != "0"
+
+
 class _PolicyLoss(torch.autograd.Function):
-    """Forward: ONE library call (prl_policy_forward) writing into two arenas.
-    Backward: one call (prl_logprob_bwd), scaled on the device by the incoming
-    gradient of the loss."""
+    """Token mode with bf16 logits that need a gradient: ONE pass over the
+    logits (prl_policy_rows_fwd_bwd) yields log-probabilities, entropy and the
+    gradient row by row; the backward only hands that gradient out (rescaled on
+    the device if the incoming loss gradient is not 1).
+    Otherwise: forward prl_policy_forward, backward prl_logprob_bwd."""
 
     @staticmethod
     def forward(ctx, logits, input_ids, position_ids, advantages, old_logprobs, loss_mask, temperature,
@@ -327,41 +337,88 @@ class _PolicyLoss(torch.autograd.Function):
         adv, old, mask = _flat32(advantages), _flat32(old_logprobs), _u8(loss_mask)
         if not (ids.numel() == pos.numel() == adv.numel() == old.numel() == mask.numel() == t):
             raise ValueError("policy_loss: every per-token tensor must hold T entries")
-        per_seq = _ratio_code(loss_config) == C.RATIO_SEQUENCE
+        ratio_code = _ratio_code(loss_config)
+        per_seq = ratio_code == C.RATIO_SEQUENCE
+        length_norm, clip = int(bool(loss_config.ratio_length_norm)), float(loss_config.clip_ratio)
         # fp32 arena: logprob, entropy, lse, g, ratio, clipped, is_clipped, seg_loss (T each) and the loss;
         # int64 arena: seg_start (T + 1) and n_seg (int32 in the last slot)
         f = torch.empty(8 * t + 1, dtype=torch.float32, device=dev)
         iarena = torch.empty(t + 2, dtype=torch.int64, device=dev)
         fp, ip = f.data_ptr(), iarena.data_ptr()
         at = lambda k: C.c_void_p(fp + 4 * t * k)
-        ws_bytes = lib.prl_logprob_workspace_bytes(t, v)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
-        with torch.cuda.device(dev), C.timed("prl_policy_forward", dev):
-            C.check(
-                lib.prl_policy_forward(
-                    C.ptr(logits), C.dtype_code(logits), t, v, logits.stride(1), C.ptr(ids), C.ptr(pos), C.ptr(adv),
-                    C.ptr(old), C.ptr(mask), int(bool(skip_masked)), temperature, _ratio_code(loss_config),
-                    int(bool(loss_config.ratio_length_norm)), float(loss_config.clip_ratio), float(loss_scale),
-                    at(0), at(1), at(2), at(8), at(4), at(5), at(6), at(3), at(7), None, C.c_void_p(ip),
-                    C.c_void_p(ip + 8 * (t + 1)), C.ptr(ws), ws_bytes, C.stream_ptr(dev),
-                ),
-                "prl_policy_forward",
-            )
+        code, st = C.dtype_code(logits), C.stream_ptr(dev)
+        single_pass = (
+            not per_seq and t > 0 and ctx.needs_input_grad[0] and _rows_kernel_enabled()
+            and logits.data_ptr() % 16 == 0
+            and bool(lib.prl_policy_rows_supported(code, t, v, logits.stride(1), code, v))
+        )
+        if single_pass:
+            dlogits = torch.empty((1, t, v), dtype=logits.dtype, device=dev)
+            with torch.cuda.device(dev):
+                with C.timed("prl_policy_rows_fwd_bwd", dev):
+                    C.check(
+                        lib.prl_policy_rows_fwd_bwd(
+                            C.ptr(logits), code, t, v, logits.stride(1), C.ptr(ids), C.ptr(adv), C.ptr(old),
+                            C.ptr(mask), int(bool(skip_masked)), temperature, clip, float(loss_scale), at(0), at(1),
+                            at(2), C.ptr(dlogits), code, v, st,
+                        ),
+                        "prl_policy_rows_fwd_bwd",
+                    )
+                with C.timed("prl_policy_tail", dev):
+                    C.check(
+                        lib.prl_policy_tail(
+                            C.ptr(pos), at(0), C.ptr(old), C.ptr(adv), C.ptr(mask), t, ratio_code, length_norm, clip,
+                            float(loss_scale), at(8), at(4), at(5), at(6), at(3), at(7), None, C.c_void_p(ip),
+                            C.c_void_p(ip + 8 * (t + 1)), st,
+                        ),
+                        "prl_policy_tail",
+                    )
+            ctx.dlogits = dlogits
+        else:
+            ws_bytes = lib.prl_logprob_workspace_bytes(t, v)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
+            with torch.cuda.device(dev), C.timed("prl_policy_forward", dev):
+                C.check(
+                    lib.prl_policy_forward(
+                        C.ptr(logits), code, t, v, logits.stride(1), C.ptr(ids), C.ptr(pos), C.ptr(adv),
+                        C.ptr(old), C.ptr(mask), int(bool(skip_masked)), temperature, ratio_code, length_norm, clip,
+                        float(loss_scale), at(0), at(1), at(2), at(8), at(4), at(5), at(6), at(3), at(7), None,
+                        C.c_void_p(ip), C.c_void_p(ip + 8 * (t + 1)), C.ptr(ws), ws_bytes, st,
+                    ),
+                    "prl_policy_forward",
+                )
         parts = f[: 8 * t].view(8, t)
         lp, ent, lse, g = parts[0].view(1, t), parts[1].view(1, t), parts[2].view(1, t), parts[3].view(1, t)
         n_aux = (t // 2 + 1 if t > 0 else 0) if per_seq else t
         ratio, clipped, is_clipped = parts[4][:n_aux], parts[5][:n_aux], parts[6][:n_aux]
         seg_start = iarena[: t + 1]
         n_seg = iarena[t + 1 :].view(torch.int32)[:1]
-        ctx.save_for_backward(logits, ids.view(1, t), lse, g)
+        ctx.single_pass = single_pass
+        if not single_pass:
+            ctx.save_for_backward(logits, ids.view(1, t), lse, g)
         ctx.temperature = temperature
         ctx.mark_non_differentiable(lp, ent, ratio, clipped, is_clipped, seg_start, n_seg)
         return f[8 * t].reshape(()), lp, ent, ratio, clipped, is_clipped, seg_start, n_seg
 
     @staticmethod
     def backward(ctx, grad_loss, *_):
-        logits, ids, lse, g = ctx.saved_tensors
         gscale = grad_loss.to(torch.float32).reshape(1).contiguous()
+        if ctx.single_pass:
+            d = ctx.dlogits
+            if d is None:
+                raise RuntimeError("policy_loss: the gradient of this loss has already been handed out; "
+                                   "a second backward through the same forward is not supported")
+            ctx.dlogits = None
+            dev = d.device
+            _, t, v = d.shape
+            with torch.cuda.device(dev), C.timed("prl_scale_rows_if_not_one", dev):
+                C.check(
+                    C.load().prl_scale_rows_if_not_one(C.ptr(d), C.dtype_code(d), t, v, v, C.ptr(gscale),
+                                                       C.stream_ptr(dev)),
+                    "prl_scale_rows_if_not_one",
+                )
+            return (d,) + (None,) * 9
+        logits, ids, lse, g = ctx.saved_tensors
         d = _launch_bwd(logits, ids, lse, g, gscale, ctx.temperature, True)
         return (d,) + (None,) * 9
 
@@ -389,8 +446,12 @@ def policy_loss(
     In sequence mode the ratio tensors have room for T // 2 + 1 samples, of
     which the first `n_seg` are filled.  `skip_masked=True` does not score
     tokens whose mask is False (their `logprobs` and `entropy` are 0, their
-    logits are never read); loss, gradient and masked statistics are the same.  Calling `.backward()` on the loss runs
-    one more pass over the logits and leaves dlogits in `logits.grad`."""
+    logits are never read); loss, gradient and masked statistics are the same.
+
+    With `ratio_type = "token"`, bf16 logits that require a gradient and a
+    vocabulary of at most 155648 the logits are read exactly once: the same
+    pass that scores a row writes its gradient, and `.backward()` only hands
+    it on.  In every other case `.backward()` runs one more pass over the logits."""
     if logits.ndim != 3 or logits.shape[0] != 1:
         raise ValueError(f"policy_loss takes one packed row, logits [1, T, V]; got {tuple(logits.shape)}")
     loss, lp, ent, ratio, clipped, is_clipped, seg_start, n_seg = _PolicyLoss.apply(

@@ -1,0 +1,216 @@
+"""The single-pass, register-resident kernel (prl_policy_rows_fwd_bwd) through the
+C ABI: against the CPU oracle, and against the two-kernel path it stands in for.
+
+Tolerances as in test_gpu_parity.py: 1e-4 for fp32 per-token values, one bf16
+unit in the last place for the gradient."""
+
+import ctypes
+import math
+
+import pytest
+import torch
+
+import prime_rl_cse_amd as prl
+from oracle import ref_cpu as O
+from prime_rl_cse_amd import _capi as C
+from tests.helpers import bf16_ulp_close, make_packed_row
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def close(a, b, atol=1e-4, rtol=1e-4):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    ok = ((a - b).abs() <= atol + rtol * b.abs()) | (a.isnan() & b.isnan()) | (a == b)
+    assert bool(ok.all()), f"max abs diff {(a - b).abs().nan_to_num().max().item():.3e}"
+
+
+def rows_call(logits, ids, adv, old, mask, temp, clip, scale, skip, stride=None):
+    """Direct C-ABI call; logits [T, >=V] bf16 on the device (row stride = logits.stride(0))."""
+    lib = C.load()
+    t = ids.numel()
+    v = logits.shape[1] if stride is None else stride[1]
+    rs = logits.stride(0)
+    assert lib.prl_policy_rows_supported(C.PRL_BF16, t, v, rs, C.PRL_BF16, v) == 1
+    lp = torch.full((t,), 7.0, device=DEV)
+    ent = torch.full((t,), 7.0, device=DEV)
+    lse = torch.full((t,), 7.0, device=DEV)
+    d = torch.full((t, v), 7.0, dtype=torch.bfloat16, device=DEV)
+    C.check(
+        lib.prl_policy_rows_fwd_bwd(
+            C.ptr(logits), C.PRL_BF16, t, v, rs, C.ptr(ids), C.ptr(adv), C.ptr(old), C.ptr(mask), int(skip),
+            temp, clip, float(scale), C.ptr(lp), C.ptr(ent), C.ptr(lse), C.ptr(d), C.PRL_BF16, v,
+            C.stream_ptr(torch.device(DEV)),
+        ),
+        "prl_policy_rows_fwd_bwd",
+    )
+    torch.cuda.synchronize()
+    return lp, ent, lse, d
+
+
+def seeded_case(seed, lengths, pad, vocab, temp, mask_p=0.7, spread=0.2):
+    gen = torch.Generator().manual_seed(seed)
+    ids, pos, mask = make_packed_row(gen, lengths, pad, vocab, mask_p=mask_p)
+    t = ids.numel()
+    logits = (torch.randn(1, t, vocab, generator=gen) * 3).to(torch.bfloat16)
+    adv = torch.randn(t, generator=gen)
+    with torch.no_grad():
+        lp0 = O.selective_log_softmax(O.shift_logits(logits.float()) / temp, ids.unsqueeze(0))[0]
+    old = lp0 + spread * torch.randn(t, generator=gen)
+    return logits, ids, pos, mask, adv, old
+
+
+# one case per register-array size the kernel is built for (2, 4, 8, 12, 16, 19 chunks per lane),
+# with vocabularies that end in the middle of a slab and in the middle of a wave
+@pytest.mark.parametrize(
+    "vocab,temp,skip",
+    [
+        (8, 1.0, False),
+        (1000, 0.7, False),
+        (16384, 1.0, True),
+        (32000, 0.6, False),
+        (50264, 1.0, True),
+        (65536 + 8, 1.3, False),
+        (98304, 1.0, False),
+        (128256, 0.9, True),
+        (151936, 1.0, False),
+        (152064, 0.6, True),
+        (155648, 1.0, False),
+    ],
+)
+def test_rows_kernel_against_oracle(vocab, temp, skip):
+    lengths, pad = [7, 5, 9], 2
+    logits, ids, pos, mask, adv, old = seeded_case(vocab, lengths, pad, vocab, temp)
+    old[3] -= 5.0  # a ratio far above the clip: that token's gradient is zero
+    t = ids.numel()
+    cfg = prl.LossConfig()
+    scale = int(mask.sum())
+    b = lambda x: x.unsqueeze(0)
+    want = O.policy_epilogue(logits, b(ids), b(pos), b(adv), b(old), b(mask), temp, cfg, scale)
+    lp, ent, lse, d = rows_call(
+        logits[0].to(DEV), ids.to(DEV), adv.to(DEV), old.to(DEV), mask.to(torch.uint8).to(DEV), temp, cfg.clip_ratio,
+        scale, skip,
+    )
+    sel = mask if skip else torch.ones_like(mask)
+    close(lp.cpu()[sel], want["logprobs"][0][sel])
+    close(ent.cpu()[sel], want["entropy"][0][sel])
+    if skip:  # unscored tokens report zeros
+        assert not lp.cpu()[~mask].any() and not ent.cpu()[~mask].any()
+    assert bf16_ulp_close(d.cpu(), want["dlogits"][0], ulps=1, atol=1e-9)
+    assert not d[t - 1].any()
+    assert abs(lse[0].item() - (0.0 if skip and not mask[0] else math.log(vocab))) < 1e-5
+
+
+@pytest.mark.parametrize("vocab,t", [(151936, 96), (32768, 300)])
+def test_rows_kernel_equals_two_kernel_path(vocab, t):
+    """policy_loss with the single-pass kernel on and off: same numbers to the
+    stated tolerances, zero rows in the same places."""
+    import os
+
+    lengths = [t // 3, t // 3, t - 2 * (t // 3)]
+    logits, ids, pos, mask, adv, old = seeded_case(5, lengths, 0, vocab, 0.8)
+    b = lambda x: x.unsqueeze(0).to(DEV)
+    cfg = prl.LossConfig()
+    out = {}
+    for flag in ("1", "0"):
+        os.environ["PRL_FUSED_ROWS"] = flag
+        try:
+            x = logits.to(DEV).requires_grad_(True)
+            loss, aux = prl.policy_loss(x, b(ids), b(pos), b(adv), b(old), b(mask), 0.8, cfg, int(mask.sum()),
+                                        skip_masked=True)
+            loss.backward()
+            out[flag] = (loss.detach(), aux, x.grad)
+        finally:
+            os.environ.pop("PRL_FUSED_ROWS", None)
+    (l1, a1, g1), (l0, a0, g0) = out["1"], out["0"]
+    close(l1, l0, atol=1e-6)
+    for key in ("logprobs", "entropy", "importance_ratio", "clipped_importance_ratio"):
+        close(a1[key], a0[key], atol=2e-5)
+    assert torch.equal(a1["is_clipped"], a0["is_clipped"])
+    assert torch.equal(a1["seg_start"], a0["seg_start"])
+    assert bf16_ulp_close(g1.cpu(), g0.cpu(), ulps=1, atol=1e-9)
+    assert torch.equal(g1 == 0, g0 == 0)
+
+
+def test_rows_kernel_row_stride_and_single_token():
+    vocab, pad = 4096, 64
+    logits, ids, pos, mask, adv, old = seeded_case(9, [6, 6], 0, vocab, 1.0)
+    t = ids.numel()
+    wide = torch.zeros(t, vocab + pad, dtype=torch.bfloat16)
+    wide[:, :vocab] = logits[0]
+    wide[:, vocab:] = 50.0  # must never be read
+    wd = wide.to(DEV)
+    cfg = prl.LossConfig()
+    want = O.policy_epilogue(logits, ids[None], pos[None], adv[None], old[None], mask[None], 1.0, cfg, 3)
+    lp, ent, _, d = rows_call(wd, ids.to(DEV), adv.to(DEV), old.to(DEV), mask.to(torch.uint8).to(DEV), 1.0,
+                              cfg.clip_ratio, 3, False, stride=(t, vocab))
+    close(lp, want["logprobs"][0])
+    close(ent, want["entropy"][0])
+    assert bf16_ulp_close(d.cpu(), want["dlogits"][0], ulps=1, atol=1e-9)
+    # T = 1: the only token is scored by the all-zero row, the only gradient row is zero
+    one = torch.ones(1, device=DEV)
+    lp, ent, lse, d = rows_call(wd[:1], ids[:1].to(DEV), one, one, one.to(torch.uint8), 1.0, 8.0, 1, False,
+                                stride=(1, vocab))
+    assert abs(lp.item() + math.log(vocab)) < 1e-6 and abs(ent.item() - math.log(vocab)) < 1e-6
+    assert not d.any()
+
+
+def test_rows_kernel_refuses_what_it_cannot_hold():
+    lib = C.load()
+    assert lib.prl_policy_rows_supported(C.PRL_F32, 16, 4096, 4096, C.PRL_F32, 4096) == 0  # fp32 rows
+    assert lib.prl_policy_rows_supported(C.PRL_BF16, 16, 1001, 1001, C.PRL_BF16, 1001) == 0  # V not a multiple of 8
+    assert lib.prl_policy_rows_supported(C.PRL_BF16, 16, 155656, 155656, C.PRL_BF16, 155656) == 0  # too wide
+    assert lib.prl_policy_rows_supported(C.PRL_BF16, 16, 4096, 4100, C.PRL_BF16, 4096) == 0  # rows not 16-byte apart
+    x = torch.zeros(16, 1001, dtype=torch.bfloat16, device=DEV)
+    z = torch.zeros(16, device=DEV)
+    rc = lib.prl_policy_rows_fwd_bwd(C.ptr(x), C.PRL_BF16, 16, 1001, 1001, C.ptr(z), C.ptr(z), C.ptr(z), C.ptr(z), 0,
+                                     1.0, 8.0, 1.0, C.ptr(z), None, None, C.ptr(x), C.PRL_BF16, 1001, None)
+    assert rc != 0 and b"not supported" in lib.prl_last_error()
+    # and policy_loss quietly takes the two-kernel path there
+    xl = torch.randn(1, 6, 1001, device=DEV).to(torch.bfloat16).requires_grad_(True)
+    i = torch.randint(0, 1001, (1, 6), device=DEV)
+    loss, _ = prl.policy_loss(xl, i, torch.arange(6, device=DEV)[None], torch.ones(1, 6, device=DEV),
+                              torch.full((1, 6), -7.0, device=DEV), torch.ones(1, 6, dtype=torch.bool, device=DEV),
+                              1.0, prl.LossConfig(), 6)
+    loss.backward()
+    assert xl.grad is not None and bool(xl.grad.isfinite().all())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("scale", [1.0, 0.375, -2.0])
+def test_scale_rows_if_not_one(dtype, scale):
+    lib = C.load()
+    gen = torch.Generator().manual_seed(3)
+    t, v, stride = 37, 1003, 1010  # odd sizes: rows not 16-byte aligned
+    buf = torch.randn(t, stride, generator=gen).to(dtype).to(DEV)
+    before = buf.clone()
+    s = torch.tensor([scale], device=DEV)
+    C.check(lib.prl_scale_rows_if_not_one(C.ptr(buf), C.dtype_code(buf), t, v, stride, C.ptr(s),
+                                          C.stream_ptr(torch.device(DEV))), "prl_scale_rows_if_not_one")
+    torch.cuda.synchronize()
+    want = (before[:, :v].float() * scale).to(dtype)
+    assert torch.equal(buf[:, :v], want)  # both factors are exact in bf16, so the product rounds once
+    assert torch.equal(buf[:, v:], before[:, v:])  # the gap between rows is untouched
+
+
+def test_incoming_gradient_other_than_one_and_second_backward():
+    logits, ids, pos, mask, adv, old = seeded_case(21, [10, 14], 0, 32000, 1.0)
+    b = lambda x: x.unsqueeze(0).to(DEV)
+    cfg = prl.LossConfig()
+    args = (b(ids), b(pos), b(adv), b(old), b(mask), 1.0, cfg, int(mask.sum()))
+    x1 = logits.to(DEV).requires_grad_(True)
+    prl.policy_loss(x1, *args)[0].backward()
+    x2 = logits.to(DEV).requires_grad_(True)
+    loss2, _ = prl.policy_loss(x2, *args)
+    (loss2 * 0.3).backward(retain_graph=True)
+    want = (x1.grad.float() * 0.3).to(torch.bfloat16)
+    assert bf16_ulp_close(x2.grad.cpu(), want.cpu(), ulps=1, atol=1e-12)
+    with pytest.raises(RuntimeError, match="second backward"):
+        (loss2 * 0.3).backward()
+    # without a gradient to compute, nothing is written for one
+    x3 = logits.to(DEV)
+    loss3, aux3 = prl.policy_loss(x3, *args)
+    assert not loss3.requires_grad
+    close(loss3, loss2, atol=1e-6)
