@@ -148,12 +148,18 @@ class KernelTimer:
     to (torch's current stream).  Meant for benchmarks: install one with
     `set_timer`, run, synchronise, read `summary()`."""
 
-    def __init__(self, only: set[str] | None = None):
+    def __init__(self, only: set[str] | None = None, every: int = 1):
         self.events: dict[str, list[tuple[torch.cuda.Event, torch.cuda.Event]]] = {}
         self.only = only  # names to time; None = every named launch
+        self.every = max(int(every), 1)  # time one launch in `every` (an event pair drains the queue around it)
+        self._seen: dict[str, int] = {}
 
     def span(self, name: str, device: torch.device):
         if self.only is not None and name not in self.only:
+            return _no_span
+        n = self._seen.get(name, 0)
+        self._seen[name] = n + 1
+        if n % self.every:
             return _no_span
         return _Span(self, name, device)
 

@@ -24,53 +24,104 @@
 // known, and fp32 rows do not fit the registers: both take the two-kernel path.
 #include "logprob_dev.h"
 
+// Build-time tunables (defaults = measured best on MI355X; tools/tune_rows.py builds and compares variants)
+#ifndef PRL_ROWS_NT_LOAD
+#define PRL_ROWS_NT_LOAD 1  // non-temporal hint on the row loads (the logits are read exactly once)
+#endif
+#ifndef PRL_ROWS_NT_STORE
+#define PRL_ROWS_NT_STORE 0  // non-temporal hint on the gradient stores (the LM-head backward reads them next)
+#endif
+#ifndef PRL_ROWS_XCD_BLOCKS
+#define PRL_ROWS_XCD_BLOCKS 1  // 1: each of the 8 XCDs works through one contiguous eighth of the rows
+#endif
+
 namespace prl {
 
 constexpr int kRowThreads = 1024;
 constexpr int kRowWaves = kRowThreads / kWave;
 constexpr int kRowMaxChunks = 19;  // 16-byte chunks per lane: 19 * 1024 * 8 = 155,648 bf16 logits
+constexpr int kTailSlabs = 4;      // the built register-array sizes are at most this far apart
 
-// The row lives in registers as packed bf16 pairs and is unpacked three times (maximum, sums,
-// gradient).  Left alone, the compiler keeps the unpacked floats of one pass for the next, which
-// doubles the register need and spills; this empty statement makes the packed values opaque so
-// that every pass unpacks again (two ALU operations per pair, no memory traffic).
-template <int NCH>
-__device__ __forceinline__ void forget_unpacked(u32x4 (&buf)[NCH]) {
-#pragma unroll
-  for (int j = 0; j < NCH; ++j) asm volatile("" : "+v"(buf[j]));
+// The row lives in registers as packed bf16 pairs and is unpacked once per pass over it.  Left
+// alone, the compiler keeps the unpacked floats of one pass for the next, which doubles the
+// register need and spills; this empty statement makes a packed chunk opaque, so that every pass
+// unpacks again (one ALU operation per element, no memory traffic).  It is also where the wait
+// for the chunk's load lands, so work on chunk j starts while later chunks are still in flight.
+__device__ __forceinline__ void touch(u32x4& v) { asm volatile("" : "+v"(v)); }
+// The same, tied to a value the previous chunk's arithmetic produced, so that the waits of later
+// chunks cannot be moved up in front of earlier chunks' work.
+__device__ __forceinline__ void touch_after(u32x4& v, float& prev) { asm volatile("" : "+v"(v), "+v"(prev)); }
+
+// Workgroup-uniform reads of one byte / one bf16 as aligned 32-bit words.  Sub-word loads have no
+// scalar form on this architecture; as vector loads they would queue behind the row loads in flight
+// and make the row wait for all of them.  The word read never leaves the aligned 4 bytes that
+// hold the requested element.  `words` is the 4-byte aligned address at or below the array, `mis`
+// the array's offset from it.
+__device__ __forceinline__ uint32_t uniform_byte(const uint32_t* __restrict__ words, int mis, int64_t i) {
+  const int64_t k = i + mis;
+  return (words[k >> 2] >> ((uint32_t)(k & 3) * 8u)) & 0xffu;
+}
+__device__ __forceinline__ float uniform_bf16(const uint32_t* __restrict__ words, int64_t i) {
+  const uint32_t w = words[i >> 1];
+  return (i & 1) ? bf16_hi(w) : bf16_lo(w);
 }
 
+// 16-byte buffer store with a scalar slab offset.  On gfx950 the store still reads its data registers
+// for a moment after it has issued: a vector ALU write to them in the very next instruction reached
+// memory instead of the intended data (seen as the first 8 bytes of a chunk replaced by an unrelated
+// 64-bit move).  The compiler's hazard table exempts exactly this form (data wider than 64 bits WITH a
+// register soffset), so the wait states are put in by hand and fenced against rescheduling.
+template <typename R>
+__device__ __forceinline__ void store_chunk(const u32x4& v, R rsrc, uint32_t voffset, int soffset) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voffset, soffset, PRL_ROWS_NT_STORE ? 2 : 0);
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 1");  // two wait states
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// One workgroup per row.  (Measured alternatives, T = 2048, V = 151936: workgroups that stay on a
+// compute unit and refill each chunk's registers with their next row while the gradient is written
+// were 8 % slower, because loads and stores retire through one in-order counter and the next row's
+// first chunk then waits for this row's stores; pulling a later row towards the caches with one
+// dword per line cost 25 %.)
 template <int NCH>
 __global__ __launch_bounds__(kRowThreads) void k_policy_rows(
     const char* __restrict__ logits, int64_t T, int64_t V, int64_t in_stride_bytes, const int64_t* __restrict__ ids,
-    const float* __restrict__ old, const float* __restrict__ adv, const uint8_t* __restrict__ mask, int skip_masked,
-    float inv_temp, float clip, float inv_scale, float* __restrict__ lp_out, float* __restrict__ ent_out,
-    float* __restrict__ lse_out, char* __restrict__ dlogits, int64_t out_stride_bytes) {
+    const float* __restrict__ old, const float* __restrict__ adv, const uint32_t* __restrict__ mask_words,
+    int mask_mis, int skip_masked, float inv_temp, float clip, float inv_scale, float* __restrict__ lp_out,
+    float* __restrict__ ent_out, float* __restrict__ lse_out, char* __restrict__ dlogits, int64_t out_stride_bytes) {
   __shared__ float red_m[kRowWaves], red_s[kRowWaves], red_w[kRowWaves];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
+#if PRL_ROWS_XCD_BLOCKS
+  // workgroups go to the XCDs round-robin (workgroup b runs on XCD b % 8); gridDim.x is a multiple of 8
+  const int64_t row = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+#else
   const int64_t row = blockIdx.x;  // row of the logits and of the gradient
-  const int64_t t = row + 1;       // the token that row predicts
-  const int64_t nchunk = V >> 3;
-  char* outp = dlogits + row * out_stride_bytes;
+#endif
+  if (row >= T) return;
+  const int64_t t = row + 1;  // the token this row predicts
+  const int nchunk = (int)(V >> 3);
+  const float c2 = inv_temp * kLog2e;
 
-  // Addressing: a uniform base per 16 KB slab of the row plus one 32-bit lane offset, so that the
-  // NCH loads (and stores) of a lane share a single address register.
+  // Addressing: buffer instructions with the row as the buffer.  A lane's NCH loads (and stores)
+  // share one 32-bit offset register, the slab offset is a scalar, and the hardware drops stores and
+  // returns zeros for loads beyond the row's V * 2 bytes, so there are no bounds branches.
   const uint32_t lane_off = (uint32_t)tid * 16u;
-  const int nchunk32 = (int)nchunk;
-
+  constexpr int kSlab = kRowThreads * 16;
+  constexpr int kRsrcFlags = 0x00020000;  // raw buffer, 32-bit data format (gfx9 family descriptor word 3)
+  const int row_bytes = (int)(V * 2);
+  const auto out_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(dlogits + row * out_stride_bytes, 0, row_bytes, kRsrcFlags);
   auto zero_row = [&]() {
     const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-      if (tid < nchunk32 - j * kRowThreads)
-        stream_store(z, reinterpret_cast<u32x4*>(outp + (int64_t)j * (kRowThreads * 16) + lane_off));
-    }
+    for (int j = 0; j < NCH; ++j) store_chunk(z, out_rsrc, lane_off, j * kSlab);
   };
 
   if (t >= T) {
     // the last row predicts nothing; its workgroup also emits token 0, which no row predicts
     if (tid == 0) {
-      if (skip_masked && mask[0] == 0)
+      if (skip_masked && uniform_byte(mask_words, mask_mis, 0) == 0)
         emit_skipped(0, lp_out, ent_out, lse_out);
       else
         emit_zero_row(V, 0, lp_out, ent_out, lse_out);
@@ -78,78 +129,114 @@ __global__ __launch_bounds__(kRowThreads) void k_policy_rows(
     zero_row();
     return;
   }
-  const bool m = mask[t] != 0;
+  const bool m = uniform_byte(mask_words, mask_mis, t) != 0;
   if (skip_masked && !m) {  // a token nobody looks at: no read, outputs 0, gradient 0
     if (tid == 0) emit_skipped(t, lp_out, ent_out, lse_out);
     zero_row();
     return;
   }
 
-  // 1. the whole row into registers; lanes past the end hold the most negative finite bf16
-  const char* rp = logits + row * in_stride_bytes;
-  const u32x4 fill = {0xff7fff7fu, 0xff7fff7fu, 0xff7fff7fu, 0xff7fff7fu};
+  // 1. the whole row into registers, issued in chunk order: the arithmetic consumes them in that order
+  const auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(logits + row * in_stride_bytes), 0,
+                                                         row_bytes, kRsrcFlags);
   u32x4 buf[NCH];
 #pragma unroll
   for (int j = 0; j < NCH; ++j) {
-    buf[j] = tid < nchunk32 - j * kRowThreads
-                 ? stream_load<true>(reinterpret_cast<const u32x4*>(rp + (int64_t)j * (kRowThreads * 16) + lane_off))
-                 : fill;
+    buf[j] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, lane_off, j * kSlab, PRL_ROWS_NT_LOAD ? 2 : 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
   const int64_t label = ids[t];
   float x_label = __builtin_nanf("");
-  if (label >= 0 && label < V) x_label = load_elem<PRL_BF16>(rp, label);
+  if (label >= 0 && label < V)
+    x_label = uniform_bf16(reinterpret_cast<const uint32_t*>(logits) + row * (in_stride_bytes >> 2), label);
   const float old_t = old[t], adv_t = adv[t];
 
-  // 2. maximum
-  forget_unpacked(buf);
-  float mx = kNegBig;
+  // Chunk j for arithmetic: waits for its load.  The row ends in one of the last kTailSlabs slabs (the
+  // host picks the smallest NCH that holds the row); there, lanes past the end get the most negative
+  // finite bf16 instead of the zeros the hardware returned.  j is a constant once the loops are
+  // unrolled, so the other slabs pay nothing for this.
+  auto chunk = [&](int j, float& prev) -> u32x4 {
+    touch_after(buf[j], prev);
+    u32x4 v = buf[j];
+    if (j >= NCH - kTailSlabs) {
+      const bool in = tid < nchunk - j * kRowThreads;
+      v.x = in ? v.x : 0xff7fff7fu;
+      v.y = in ? v.y : 0xff7fff7fu;
+      v.z = in ? v.z : 0xff7fff7fu;
+      v.w = in ? v.w : 0xff7fff7fu;
+    }
+    return v;
+  };
+  // block-wide sums of 2^(x c2 - M) and x 2^(x c2 - M) over the registers
+  auto sums = [&](float M, float& s_out, float& w_out) {
+    float es[4] = {0.0f, 0.0f, 0.0f, 0.0f}, ws[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-  for (int j = 0; j < NCH; ++j) {
+    for (int j = 0; j < NCH; ++j) {
+      float x[8];
+      decode16_raw<PRL_BF16>(chunk(j, ws[3]), x);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float e = fast_exp2(fmaf(x[i], c2, -M));
+        es[i & 3] += e;
+        ws[i & 3] = fmaf(x[i], e, ws[i & 3]);
+      }
+    }
+    float s = wave_sum((es[0] + es[2]) + (es[1] + es[3]));
+    float w = wave_sum((ws[0] + ws[2]) + (ws[1] + ws[3]));
+    if (lane == 0) {
+      red_s[wid] = s;
+      red_w[wid] = w;
+    }
+    __syncthreads();
+    s = red_s[0];
+    w = red_w[0];
+#pragma unroll
+    for (int i = 1; i < kRowWaves; ++i) {
+      s += red_s[i];
+      w += red_w[i];
+    }
+    s_out = s;
+    w_out = w;
+  };
+  auto block_max = [&](float mx) -> float {
+    mx = wave_max(mx);
+    if (lane == 0) red_m[wid] = mx;
+    __syncthreads();
+    mx = red_m[0];
+#pragma unroll
+    for (int i = 1; i < kRowWaves; ++i) mx = fmaxf(mx, red_m[i]);
+    return mx;
+  };
+
+  // 2. Reference point of the exponentials: the maximum over every lane's first chunk (8192 logits).
+  //    Any M <= max + ~100/c2 gives the same sums up to rounding; an M so far below the true maximum
+  //    that the sum overflows is caught below and replaced by the exact maximum.
+  float mx = kNegBig;
+  {
     float x[8];
-    decode16_raw<PRL_BF16>(buf[j], x);
+    decode16_raw<PRL_BF16>(chunk(0, mx), x);
 #pragma unroll
     for (int i = 0; i < 8; ++i) mx = fmaxf(mx, x[i]);
   }
-  mx = wave_max(mx);
-  if (lane == 0) red_m[wid] = mx;
-  __syncthreads();
-  mx = red_m[0];
+  float M = block_max(mx) * c2;  // c2 > 0: the largest logit gives the largest scaled logit
+  float s, w;
+  sums(M, s, w);
+  if (!(s <= 3.0e38f) || !(s > 0.0f)) {  // overflow (or a NaN / -inf sample): exact two-pass soft-max
+    __syncthreads();                     // every wave has read the first round's sums before they are rewritten
+    mx = kNegBig;
 #pragma unroll
-  for (int i = 1; i < kRowWaves; ++i) mx = fmaxf(mx, red_m[i]);
-  const float c2 = inv_temp * kLog2e;
-  const float M = mx * c2;  // c2 > 0: the largest logit gives the largest scaled logit
-
-  // 3. s = sum 2^(y - M), w = sum x 2^(y - M) with y = x * c2
-  forget_unpacked(buf);
-  float es[4] = {0.0f, 0.0f, 0.0f, 0.0f}, ws[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int j = 0; j < NCH; ++j) {
+      float x[8];
+      decode16_raw<PRL_BF16>(chunk(j, mx), x);
 #pragma unroll
-  for (int j = 0; j < NCH; ++j) {
-    float x[8];
-    decode16_raw<PRL_BF16>(buf[j], x);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float e = fast_exp2(fmaf(x[i], c2, -M));
-      es[i & 3] += e;
-      ws[i & 3] = fmaf(x[i], e, ws[i & 3]);
+      for (int i = 0; i < 8; ++i) mx = fmaxf(mx, x[i]);
     }
-  }
-  float s = wave_sum((es[0] + es[2]) + (es[1] + es[3]));
-  float w = wave_sum((ws[0] + ws[2]) + (ws[1] + ws[3]));
-  if (lane == 0) {
-    red_s[wid] = s;
-    red_w[wid] = w;
-  }
-  __syncthreads();
-  s = red_s[0];
-  w = red_w[0];
-#pragma unroll
-  for (int i = 1; i < kRowWaves; ++i) {
-    s += red_s[i];
-    w += red_w[i];
+    M = block_max(mx) * c2;
+    sums(M, s, w);
   }
 
-  // 4. the token's values and its loss gradient (same expressions as the loss kernels, so that the
-  //    g they report is the g used here)
+  // 3. the token's values and its loss gradient (same expressions as the loss kernels, so that the g
+  //    they report is the g used here)
   const float lse2 = M + fast_log2(s);
   const float lse = lse2 * kLn2;
   const float lp = x_label * inv_temp - lse;
@@ -167,27 +254,29 @@ __global__ __launch_bounds__(kRowThreads) void k_policy_rows(
     return;
   }
 
-  // 5. the gradient row, from the registers
-  forget_unpacked(buf);
-  const int label_chunk = (int)(label >> 3), label_elem = (int)(label & 7);
+  // 4. The gradient row from the registers.  Away from the label, d = -gi * 2^(x c2 - lse2)
+  //    = -+2^(x c2 - lse2 + log2|gi|): the factor goes into the exponent and the sign onto the packed
+  //    pair, which leaves one fma and one exp per element.
+  const float shift2 = fast_log2(fabsf(gi)) - lse2;
+  const uint32_t sign2 = gi > 0.0f ? 0x80008000u : 0u;  // d has the sign of -gi (a NaN gi gives NaN exponents)
 #pragma unroll
   for (int j = 0; j < NCH; ++j) {
-    if (tid < nchunk32 - j * kRowThreads) {
-      float y[8], d[8];
-      decode16<PRL_BF16>(buf[j], c2, y);
+    touch(buf[j]);
+    float x[8], d[8];
+    decode16_raw<PRL_BF16>(buf[j], x);  // lanes past the row's end work on zeros; their stores are dropped
 #pragma unroll
-      for (int i = 0; i < 8; ++i) d[i] = -gi * fast_exp2(y[i] - lse2);
-      if (label_chunk == j * kRowThreads + tid) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) d[i] += (label_elem == i) ? gi : 0.0f;
-      }
-      u32x4 v;
-      v.x = pack_bf16(d[0], d[1]);
-      v.y = pack_bf16(d[2], d[3]);
-      v.z = pack_bf16(d[4], d[5]);
-      v.w = pack_bf16(d[6], d[7]);
-      stream_store(v, reinterpret_cast<u32x4*>(outp + (int64_t)j * (kRowThreads * 16) + lane_off));
-    }
+    for (int i = 0; i < 8; ++i) d[i] = fast_exp2(fmaf(x[i], c2, shift2));
+    u32x4 v;
+    v.x = pack_bf16(d[0], d[1]) | sign2;
+    v.y = pack_bf16(d[2], d[3]) | sign2;
+    v.z = pack_bf16(d[4], d[5]) | sign2;
+    v.w = pack_bf16(d[6], d[7]) | sign2;
+    store_chunk(v, out_rsrc, lane_off, j * kSlab);
+  }
+  // the label's element: gi * (1 - p), written by the lane that stored its chunk, after that store
+  if (label >= 0 && label < V && tid == (int)((label >> 3) & (kRowThreads - 1))) {
+    const float p = fast_exp2(fmaf(x_label, c2, -lse2));
+    reinterpret_cast<uint16_t*>(dlogits + row * out_stride_bytes)[label] = one_bf16(fmaf(-gi, p, gi));
   }
 }
 
@@ -247,12 +336,19 @@ extern "C" int prl_policy_rows_fwd_bwd(const void* logits, int logits_dtype, int
   const float scale = loss_scale > 1.0f ? loss_scale : 1.0f;  // max(loss_scale, 1)
   const float inv_temp = 1.0f / temperature;
   const int need = chunks_needed(V);
+#if PRL_ROWS_XCD_BLOCKS
+  const dim3 grid((unsigned)((T + 7) / 8 * 8)), block(kRowThreads);  // workgroups past the last row return at once
+#else
   const dim3 grid((unsigned)T), block(kRowThreads);
+#endif
+  const int mask_mis = (int)(reinterpret_cast<uintptr_t>(mask) & 3);
+  const uint32_t* mask_words = reinterpret_cast<const uint32_t*>(mask - mask_mis);
   hipStream_t st = (hipStream_t)stream;
 #define PRL_ROWS(N)                                                                                                \
   hipLaunchKernelGGL((k_policy_rows<N>), grid, block, 0, st, (const char*)logits, T, V, row_stride * 2, ids, old, \
-                     adv, mask, skip_masked ? 1 : 0, inv_temp, clip_ratio, 1.0f / scale, logprob, entropy, lse,   \
+                     adv, mask_words, mask_mis, skip_masked ? 1 : 0, inv_temp, clip_ratio, 1.0f / scale, logprob, entropy, lse,   \
                      (char*)dlogits, out_row_stride * 2)
+  // sizes at most kTailSlabs = 4 apart, so that the row always ends in the last 4 slabs of its kernel
   if (need <= 2)
     PRL_ROWS(2);
   else if (need <= 4)
