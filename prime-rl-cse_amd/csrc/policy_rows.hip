@@ -29,10 +29,14 @@
 #define PRL_ROWS_NT_LOAD 1  // non-temporal hint on the row loads (the logits are read exactly once)
 #endif
 #ifndef PRL_ROWS_NT_STORE
-#define PRL_ROWS_NT_STORE 0  // non-temporal hint on the gradient stores (the LM-head backward reads them next)
+#define PRL_ROWS_NT_STORE 1  // non-temporal hint on the gradient stores (3 % faster; the 622 MB written exceed the 256 MB Infinity Cache anyway)
 #endif
 #ifndef PRL_ROWS_XCD_BLOCKS
 #define PRL_ROWS_XCD_BLOCKS 1  // 1: each of the 8 XCDs works through one contiguous eighth of the rows
+#endif
+
+#ifndef PRL_ROWS_TRACE
+#define PRL_ROWS_TRACE 0  // measurement aid: 1 writes phase durations (in 10 ns ticks) over logprob / entropy / lse
 #endif
 
 namespace prl {
@@ -99,6 +103,9 @@ __global__ __launch_bounds__(kRowThreads) void k_policy_rows(
   const int64_t row = blockIdx.x;  // row of the logits and of the gradient
 #endif
   if (row >= T) return;
+#if PRL_ROWS_TRACE
+  const uint64_t tick0 = wall_clock64();
+#endif
   const int64_t t = row + 1;  // the token this row predicts
   const int nchunk = (int)(V >> 3);
   const float c2 = inv_temp * kLog2e;
@@ -219,8 +226,14 @@ __global__ __launch_bounds__(kRowThreads) void k_policy_rows(
     for (int i = 0; i < 8; ++i) mx = fmaxf(mx, x[i]);
   }
   float M = block_max(mx) * c2;  // c2 > 0: the largest logit gives the largest scaled logit
+#if PRL_ROWS_TRACE
+  const uint64_t tick1 = wall_clock64();  // the first chunk has arrived in every wave
+#endif
   float s, w;
   sums(M, s, w);
+#if PRL_ROWS_TRACE
+  const uint64_t tick2 = wall_clock64();  // all chunks arrived and summed
+#endif
   if (!(s <= 3.0e38f) || !(s > 0.0f)) {  // overflow (or a NaN / -inf sample): exact two-pass soft-max
     __syncthreads();                     // every wave has read the first round's sums before they are rewritten
     mx = kNegBig;
@@ -273,6 +286,13 @@ __global__ __launch_bounds__(kRowThreads) void k_policy_rows(
     v.w = pack_bf16(d[6], d[7]) | sign2;
     store_chunk(v, out_rsrc, lane_off, j * kSlab);
   }
+#if PRL_ROWS_TRACE
+  if (tid == 0) {
+    lp_out[t] = (float)(tick1 - tick0);
+    ent_out[t] = (float)(tick2 - tick1);
+    lse_out[t] = (float)(wall_clock64() - tick2);
+  }
+#endif
   // the label's element: gi * (1 - p), written by the lane that stored its chunk, after that store
   if (label >= 0 && label < V && tid == (int)((label >> 3) & (kRowThreads - 1))) {
     const float p = fast_exp2(fmaf(x_label, c2, -lse2));

@@ -19,9 +19,10 @@ TUNE = LIB / "tune"
 
 VARIANTS = {
     "base": {}, "base_again": {},
-    "nt_store": {"PRL_ROWS_NT_STORE": 1},
+    "plain_store": {"PRL_ROWS_NT_STORE": 0},
     "plain_load": {"PRL_ROWS_NT_LOAD": 0},
     "rows_in_launch_order": {"PRL_ROWS_XCD_BLOCKS": 0},
+    "trace": {"PRL_ROWS_TRACE": 1},
 }
 
 
@@ -79,7 +80,7 @@ def run(rounds: int = 15, t: int = 2048, v: int = 151936) -> None:
     torch.cuda.synchronize()
     old.copy_(lp)
     times = {tag: [] for tag in libs}
-    order = list(libs)
+    order = [tag for tag in libs if tag != "trace"]
     for _ in range(rounds):
         random.shuffle(order)
         for tag in order:
@@ -90,6 +91,13 @@ def run(rounds: int = 15, t: int = 2048, v: int = 151936) -> None:
             b.record()
             torch.cuda.synchronize()
             times[tag].append(a.elapsed_time(b) / 5)
+    if "trace" in libs:
+        call(libs["trace"])
+        torch.cuda.synchronize()
+        for name, arr in (("launch -> first chunk summed", lp), ("rest of the sums pass", ent), ("gradient pass", lse)):
+            x = arr[1:].double() / 100.0
+            print(f"trace: {name:30s} mean {x.mean():6.2f} us  min {x.min():6.2f}  max {x.max():6.2f}")
+        del libs["trace"], times["trace"]
     nbytes = (2 * t - 1) * v * 2
     for tag, ts in sorted(times.items(), key=lambda kv: statistics.median(kv[1])):
         med = statistics.median(ts)
