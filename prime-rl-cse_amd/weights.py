@@ -214,3 +214,121 @@ class WeightPublisher:
         path = get_step_path(self.weights_dir, old)
         shutil.rmtree(path, ignore_errors=True)
         return path
+
+
+# --------------------------------------------------------------------------- device-to-device hand-off
+
+
+def _aligned(n: int, a: int = 256) -> int:
+    return (n + a - 1) // a * a
+
+
+class WeightBroadcast:
+    """Trainer -> inference weights without the file system: ONE broadcast of a flat
+    bucket per publication, over RCCL (xGMI inside a node) on the publication stream.
+
+    The reference moves weights through `weights/step_N/pytorch_model.bin` and an HTTP
+    call that makes every inference worker `torch.load` the file
+    (src/prime_rl/trainer/weights.py:130-209, src/prime_rl/orchestrator/client.py:63-86,
+    src/prime_rl/inference/vllm/worker.py:14-30).  This is the device path beside it:
+    the trainer's rank 0 and the inference ranks form one process group; the sender
+    packs the gathered bf16 tensors into one contiguous bucket (256-byte aligned
+    slots) and broadcasts the bucket, preceded by a 2-word header (step, bytes).
+    xGMI links are point to point, so one large message per publication is the shape
+    that uses them well: 1.2 GB for Qwen3-0.6B instead of 311 small ones.
+
+    The receiver owns TWO buckets and fills them alternately: the tensors `receive()`
+    returned last time stay valid (the engine can keep decoding with them) while the
+    next publication lands in the other bucket.
+
+    Sender:    ch = WeightBroadcast(group, src=0, device=dev); publisher.add_device_subscriber(ch.send)
+    Receiver:  ch = WeightBroadcast(group, src=0, device=dev); step, state = ch.receive()
+    The first exchange also carries the manifest (names, shapes, dtypes, offsets) as a
+    pickled object through the group's host path; later ones are header + bucket only.
+    A header with step -1 (`close()`) tells receivers to stop.
+    """
+
+    def __init__(self, group: Any, src: int, device: torch.device | str):
+        self.group, self.src, self.device = group, src, torch.device(device)
+        self.is_sender = dist.get_rank() == src
+        self.is_member = dist.get_rank(group) >= 0 if group is not None else True
+        self.manifest: list[tuple[str, tuple[int, ...], torch.dtype, int, int]] | None = None
+        self.total_bytes = 0
+        self._buckets: list[Tensor] = []
+        self._turn = 0
+
+    # -- both sides
+
+    def _set_manifest(self, manifest: list[tuple[str, tuple[int, ...], torch.dtype, int, int]]) -> None:
+        self.manifest = manifest
+        self.total_bytes = max((off + _aligned(nbytes) for _, _, _, off, nbytes in manifest), default=0)
+        n = 1 if self.is_sender else 2
+        self._buckets = [torch.empty(max(self.total_bytes, 1), dtype=torch.uint8, device=self.device)
+                         for _ in range(n)]
+
+    def _views(self, bucket: Tensor) -> dict[str, Tensor]:
+        out = {}
+        for name, shape, dtype, off, nbytes in self.manifest or []:
+            out[name] = bucket[off : off + nbytes].view(dtype).view(shape)
+        return out
+
+    # -- sender
+
+    def send(self, state: dict[str, Tensor], step: int) -> None:
+        """Broadcast `state` (tensors on `device`).  Runs on the caller's current stream; as a
+        `WeightPublisher` device subscriber that is the publication side stream.  Ranks outside the
+        group return at once."""
+        if not self.is_member:
+            return
+        if not self.is_sender:
+            raise RuntimeError("WeightBroadcast.send called on a rank that is not the source")
+        if self.manifest is None:
+            manifest, off = [], 0
+            for name, t in state.items():
+                nbytes = t.numel() * t.element_size()
+                manifest.append((name, tuple(t.shape), t.dtype, off, nbytes))
+                off += _aligned(nbytes)
+            dist.broadcast_object_list([manifest], src=self.src, group=self.group)
+            self._set_manifest(manifest)
+        elif [m[0] for m in self.manifest] != list(state.keys()):
+            raise RuntimeError("WeightBroadcast: the set of tensors changed between publications")
+        bucket = self._buckets[0]
+        views = self._views(bucket)
+        with torch.no_grad():
+            for name, t in state.items():
+                views[name].copy_(t, non_blocking=True)
+        header = torch.tensor([step, self.total_bytes], dtype=torch.int64).to(self.device, non_blocking=True)
+        dist.broadcast(header, src=self.src, group=self.group)
+        dist.broadcast(bucket, src=self.src, group=self.group)
+
+    def close(self) -> None:
+        if self.is_member and self.is_sender:
+            header = torch.tensor([-1, 0], dtype=torch.int64).to(self.device)
+            if self.manifest is None:
+                dist.broadcast_object_list([[]], src=self.src, group=self.group)
+                self._set_manifest([])
+            dist.broadcast(header, src=self.src, group=self.group)
+
+    # -- receiver
+
+    def receive(self) -> tuple[int, dict[str, Tensor]] | None:
+        """Block until the next publication has been enqueued into this rank's idle bucket; returns
+        (step, tensors viewing that bucket), or None after `close()`.  With RCCL the tensors are ready
+        in stream order on the current stream."""
+        if self.is_sender:
+            raise RuntimeError("WeightBroadcast.receive called on the source rank")
+        if self.manifest is None:
+            box: list[Any] = [None]
+            dist.broadcast_object_list(box, src=self.src, group=self.group)
+            self._set_manifest([tuple(m) for m in box[0]])
+        header = torch.empty(2, dtype=torch.int64, device=self.device)
+        dist.broadcast(header, src=self.src, group=self.group)
+        step, nbytes = (int(x) for x in header.tolist())
+        if step < 0:
+            return None
+        if nbytes != self.total_bytes:
+            raise RuntimeError(f"WeightBroadcast: sender announces {nbytes} bytes, manifest says {self.total_bytes}")
+        bucket = self._buckets[self._turn]
+        self._turn ^= 1
+        dist.broadcast(bucket, src=self.src, group=self.group)
+        return step, self._views(bucket)
