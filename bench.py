@@ -106,7 +106,7 @@ def run_step(rows, cfg, with_stats: bool):
         logits.grad = None
         loss, aux = prl.policy_loss(logits, r["input_ids"], r["position_ids"], r["advantages"], r["logprobs"],
                                     r["loss_mask"], r["temperature"], cfg, loss_scale)
-        loss.backward()
+        loss.backward(prl.unit_gradient(loss.device))
         out = logits.grad
         if with_stats:
             m = r["loss_mask"]

@@ -18,6 +18,7 @@ from .loss import (  # noqa: F401
     segments_from_position_ids,
     selective_log_softmax,
     shift_logits,
+    unit_gradient,
 )
 from .world import get_world, reset_world  # noqa: F401
 from .utils import Tensors, flexible_all_gather, get_response_lengths, masked_stats  # noqa: F401

@@ -308,6 +308,25 @@ def _u8(mask: Tensor) -> Tensor:
     return m.contiguous().view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8).contiguous()
 
 
+_UNIT_GRADIENTS: dict[torch.device, Tensor] = {}
+
+
+def unit_gradient(device: torch.device | str) -> Tensor:
+    """A constant 1.0 on `device` to pass to `loss.backward(...)`.
+
+    `loss.backward()` without an argument makes autograd create a fresh tensor of ones whose VALUE the
+    backward of `policy_loss` cannot know without a host synchronisation, so it launches a (tiny) kernel that
+    looks at it on the device.  When the gradient that arrives IS this constant (same storage), that launch
+    is skipped.  Do not modify the returned tensor."""
+    dev = torch.device(device)
+    if dev.type == "cuda" and dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    t = _UNIT_GRADIENTS.get(dev)
+    if t is None:
+        t = _UNIT_GRADIENTS[dev] = torch.ones((), dtype=torch.float32, device=dev)
+    return t
+
+
 def _rows_kernel_enabled() -> bool:
     """The register-resident single-pass kernel is used whenever it applies; PRL_FUSED_ROWS=0 switches it off
     (for A/B measurements against the two-kernel path)."""
@@ -410,6 +429,9 @@ class _PolicyLoss(torch.autograd.Function):
                                    "a second backward through the same forward is not supported")
             ctx.dlogits = None
             dev = d.device
+            unit = _UNIT_GRADIENTS.get(dev)
+            if unit is not None and grad_loss.data_ptr() == unit.data_ptr():
+                return (d,) + (None,) * 9  # the caller passed unit_gradient(): known to be 1
             _, t, v = d.shape
             with torch.cuda.device(dev), C.timed("prl_scale_rows_if_not_one", dev):
                 C.check(

@@ -25,7 +25,7 @@ from torch import Tensor, nn
 from .batch import to_device
 from .config import LossConfig
 from .data import MicroBatch
-from .loss import policy_loss
+from .loss import policy_loss, unit_gradient
 from .utils import Tensors
 
 # Literal architecture dimensions (there is no hub access where this runs).  The
@@ -140,7 +140,7 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, micro_batches
         loss, aux = policy_loss(logits, mb["input_ids"], mb["position_ids"], mb["advantages"], mb["logprobs"],
                                 mb["loss_mask"], mb["temperature"], loss_config, loss_scale, skip_masked=True)
         del logits
-        loss.backward()
+        loss.backward(unit_gradient(loss.device))
         mask = mb["loss_mask"]
         tensors.add("probs", aux["logprobs"], mask, exp=True)
         tensors.add("old_probs", mb["logprobs"], mask, exp=True)

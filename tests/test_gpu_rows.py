@@ -211,6 +211,17 @@ def test_incoming_gradient_other_than_one_and_second_backward():
     assert bf16_ulp_close(x2.grad.cpu(), want.cpu(), ulps=1, atol=1e-12)
     with pytest.raises(RuntimeError, match="second backward"):
         (loss2 * 0.3).backward()
+    # the constant from unit_gradient() is recognised by its storage: same result, no rescale launch
+    x4 = logits.to(DEV).requires_grad_(True)
+    loss4, _ = prl.policy_loss(x4, *args)
+    timer = C.KernelTimer()
+    C.set_timer(timer)
+    try:
+        loss4.backward(prl.unit_gradient(DEV))
+    finally:
+        C.set_timer(None)
+    torch.cuda.synchronize()
+    assert torch.equal(x4.grad, x1.grad) and "prl_scale_rows_if_not_one" not in timer.summary()
     # without a gradient to compute, nothing is written for one
     x3 = logits.to(DEV)
     loss3, aux3 = prl.policy_loss(x3, *args)
