@@ -1,0 +1,153 @@
+"""The packed-row shapes of the other recipes (debug, wordle 1.7B, hendrycks 7B, the
+32B recipe) through the whole hot path as the trainer drives it: rollouts ->
+group advantages -> first-fit-decreasing packing -> HIP path on bf16 logits.
+
+What is compared with what:
+  * sample boundaries: bit-exact against the oracle's get_response_lengths;
+  * logprob, entropy: the oracle's selective_log_softmax / compute_entropy (fp32 torch on
+    the CPU, as the reference) on slabs of rows; every row for T <= 4096, a seeded
+    sample of 1024 rows for T = 16384; tolerance 1e-4.  The reference's fp32 entropy
+    formula (softmax, multiply, sum) is itself up to 4e-4 away from the exact value at
+    temperature 0.6 and V = 152 K (measured against float64), so the entropy is held to
+    1e-4 of the float64 value and to 1e-4 plus the reference's own error of the fp32 one;
+  * loss, ratios, clip flags: the oracle's compute_loss on the per-sample splits;
+  * gradient: autograd through the oracle's selective_log_softmax on a sample of rows,
+    bf16 one unit in the last place; plus the size-independent properties (rows of
+    unscored tokens are zero, every row sums to zero, the dropped last row is zero)."""
+
+import math
+
+import pytest
+import torch
+
+import prime_rl_cse_amd as prl
+from oracle import ref_cpu as O
+from tests.helpers import bf16_ulp_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+# name, vocabulary, row capacity (micro_batch_size * seq_len), rollouts, rollouts per example, temperature, turns
+RECIPES = [
+    ("debug_1x128", 151936, 128, 4, 2, 1.0, 1),
+    ("wordle_qwen3_1p7b_1x4096", 151936, 4096, 48, 16, 1.0, 4),
+    ("hendrycks_7b_2x2048", 152064, 4096, 32, 16, 1.0, 1),
+    ("recipe_32b_8x2048_temp0p6", 152064, 16384, 64, 8, 0.6, 1),
+]
+
+
+def make_rollouts(gen, n, group, capacity, vocab, turns):
+    """Synthetic rollouts shaped like what the orchestrator hands to prepare_batch
+    (src/prime_rl/orchestrator/orchestrator.py:238-263): masked prompt, completion with
+    sampler log-probabilities, for multi-turn environments completion stretches whose mask
+    is 0 (environment tokens)."""
+    rewards = torch.rand(n, generator=gen).round().tolist()
+    lens = torch.randint(max(capacity // 40, 4), max(capacity // 6, 8), (n,), generator=gen).tolist()
+    adv = prl.compute_advantages(rewards, lens, group, "drgrpo", DEV)
+    out = []
+    for i in range(n):
+        total = min(lens[i], capacity)
+        p = max(total // 4, 1)
+        c = total - p
+        cmask = torch.ones(c, dtype=torch.long)
+        if turns > 1:  # environment replies inside the completion are not trained on
+            for k in range(1, turns):
+                a = c * k // turns
+                cmask[a : a + max(c // (4 * turns), 1)] = 0
+        out.append(prl.Rollout(
+            problem_id=i // group,
+            prompt_tokens=torch.randint(0, vocab, (p,), generator=gen).tolist(), prompt_mask=[0] * p,
+            completion_tokens=torch.randint(0, vocab, (c,), generator=gen).tolist(), completion_mask=cmask.tolist(),
+            completion_logprobs=(-torch.rand(c, generator=gen) * 3).tolist(), is_truncated=False,
+            reward=rewards[i], advantage=adv[i],
+        ))
+    return out
+
+
+@pytest.mark.parametrize("name,vocab,capacity,n,group,temp,turns", RECIPES, ids=[r[0] for r in RECIPES])
+def test_recipe_shape(name, vocab, capacity, n, group, temp, turns):
+    gen = torch.Generator().manual_seed(sum(name.encode()) * 7919)
+    rollouts = make_rollouts(gen, n, group, capacity, vocab, turns)
+    rows = prl.prepare_batch(rollouts, temp, None, n, 1, capacity, 1)[0]
+    mb = max(rows, key=lambda r: r["input_ids"].shape[1])  # the fullest packed row
+    t = mb["input_ids"].shape[1]
+    assert 2 <= t <= capacity
+    print(f"{name}: T={t} V={vocab}", flush=True)
+    ids, pos, mask = mb["input_ids"][0], mb["position_ids"][0], mb["loss_mask"][0]
+    adv = mb["advantages"][0]
+    lengths = O.get_response_lengths(pos)
+
+    dgen = torch.Generator(device=DEV).manual_seed(7)
+    logits = torch.empty(1, t, vocab, dtype=torch.bfloat16, device=DEV)
+    for a in range(0, t, 1024):
+        b = min(a + 1024, t)
+        logits[0, a:b] = (torch.randn(b - a, vocab, generator=dgen, device=DEV) * 2.5).to(torch.bfloat16)
+    # sampler log-probabilities near the policy's own, so that ratios are near 1 and a few tokens clip
+    with torch.no_grad():
+        lp_now = prl.selective_log_softmax(prl.shift_logits(logits) / temp, ids[None].to(DEV))[0].cpu()
+    old = lp_now + 0.3 * torch.randn(t, generator=gen)
+    old[mask.nonzero()[::97].flatten()] -= 4.0  # every 97th trained token far above the clip
+    scale = int(mask.sum())
+    cfg = prl.LossConfig()
+
+    x = logits.requires_grad_(True)
+    d = lambda v: v[None].to(DEV)
+    loss, aux = prl.policy_loss(x, d(ids), d(pos), d(adv), d(old), d(mask), temp, cfg, scale, skip_masked=True)
+    loss.backward(prl.unit_gradient(DEV))
+    torch.cuda.synchronize()
+
+    # sample boundaries
+    k = int(aux["n_seg"].item())
+    starts = aux["seg_start"][: k + 1].cpu()
+    assert (starts[1:] - starts[:-1]).tolist() == lengths
+
+    # logprob and entropy on slabs of rows against the oracle
+    if t <= 4096:
+        tokens = torch.arange(1, t)
+    else:
+        tokens = torch.randperm(t - 1, generator=gen)[:1024].sort().values + 1
+    tokens = tokens[mask[tokens]]  # unscored tokens report zeros, checked below
+    lp_hip, ent_hip = aux["logprobs"][0].cpu(), aux["entropy"][0].cpu()
+    lp_ref = torch.empty(tokens.numel())
+    ent_ref = torch.empty(tokens.numel())
+    ent_f64 = torch.empty(tokens.numel(), dtype=torch.float64)
+    for a in range(0, tokens.numel(), 256):
+        tk = tokens[a : a + 256]
+        xs = (logits.detach()[0, (tk - 1).to(DEV)].float().cpu() / temp)[None]
+        lp_ref[a : a + 256] = O.selective_log_softmax(xs, ids[tk][None])[0]
+        ent_ref[a : a + 256] = O.compute_entropy(xs)[0]
+        xd = xs[0].double()
+        ent_f64[a : a + 256] = torch.logsumexp(xd, -1) - (torch.softmax(xd, -1) * xd).sum(-1)
+    assert (lp_hip[tokens] - lp_ref).abs().max().item() < 1e-4
+    assert (ent_hip[tokens].double() - ent_f64).abs().max().item() < 1e-4
+    ref_err = (ent_ref.double() - ent_f64).abs()
+    assert bool(((ent_hip[tokens] - ent_ref).abs().double() <= 1e-4 + ref_err).all())
+    assert not lp_hip[~mask].any() and not ent_hip[~mask].any()
+    if mask[0]:
+        assert abs(lp_hip[0].item() + math.log(vocab)) < 1e-5
+
+    # loss, ratios and clip flags: the oracle's compute_loss on the per-sample splits of the HIP logprobs
+    lp_in = lp_hip.clone().requires_grad_(True)
+    want_loss, want = O.compute_loss(lp_in.split(lengths), old.split(lengths), adv.split(lengths), mask.split(lengths),
+                                     O.LossConfig(), scale)
+    want_loss.backward()
+    g = lp_in.grad
+    assert abs(loss.item() - want_loss.item()) <= 1e-4 * max(1.0, abs(want_loss.item()))
+    sel = mask
+    for key in ("importance_ratio", "clipped_importance_ratio", "is_clipped"):
+        got = aux[key].cpu()
+        assert torch.allclose(got[sel], want[key][sel], rtol=1e-4, atol=1e-6), key
+    assert int(want["is_clipped"][mask].sum()) > 0  # the clip fired somewhere
+
+    # gradient: sampled rows against autograd through the oracle, all rows by property
+    grad = x.grad[0]
+    pick = tokens[torch.randperm(tokens.numel(), generator=gen)[:96]]
+    xs = (logits.detach()[0, (pick - 1).to(DEV)].float().cpu())[None].requires_grad_(True)
+    O.selective_log_softmax(xs / temp, ids[pick][None]).backward(g[pick][None])
+    assert bf16_ulp_close(grad[(pick - 1).to(DEV)].cpu(), xs.grad[0].to(torch.bfloat16), ulps=1, atol=1e-9)
+    assert not grad[t - 1].any()
+    dead = ((g == 0).nonzero().flatten() - 1)
+    dead = dead[dead >= 0].to(DEV)
+    assert not grad[dead].any()
+    sums = torch.stack([grad[a : a + 512].float().sum(dim=-1).abs().max() for a in range(0, t, 512)]).max().item()
+    assert sums < 5e-5
