@@ -171,3 +171,46 @@ def test_trainer_entry_point_on_rollout_files(tmp_path, monkeypatch):
     assert len(history) == 2 and history[0]["optim/grad_norm"] > 0
     assert "importance_ratio/mean" not in history[0]  # per-sample ratios are not logged per token
     assert (tmp_path / "weights" / "step_2" / "pytorch_model.bin").exists()
+
+
+def test_statistics_exchange_runs_over_rccl(monkeypatch):
+    """The between-pass all-reduces of `Tensors` (int32 histograms, int64 counts, float64 moments, int32
+    extrema with MAX) through the RCCL backend.  One rank is all this box has, so the group has one member and
+    the package is told the world is larger: every collective is issued for real and must leave the numbers
+    of the single-rank path unchanged."""
+    import torch.distributed as dist
+
+    from prime_rl_cse_amd import utils as U
+
+    _single_rank_env(monkeypatch, 29763)
+    dist.init_process_group("nccl", device_id=torch.device("cuda:0"))
+    try:
+        gen = torch.Generator().manual_seed(5)
+        xs = [torch.randn(5000, generator=gen).to("cuda:0") for _ in range(3)]
+        ms = [(torch.rand(5000, generator=gen) < 0.6).to("cuda:0") for _ in range(3)]
+
+        def run():
+            t = prl.Tensors()
+            for x, m in zip(xs, ms):
+                t.add("a", x, m)
+                t.add("b", x, m, exp=True)
+                t.add("c", x[:7])
+            return t.compute_stats()
+
+        alone = run()
+
+        class LargerWorld:
+            def __getattr__(self, name):
+                return getattr(dist, name)
+
+            def get_world_size(self, *a, **k):
+                return 2
+
+        monkeypatch.setattr(U, "dist", LargerWorld())
+        exchanged = run()
+        assert exchanged.keys() == alone.keys()
+        for k in alone:
+            assert exchanged[k] == alone[k], k
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
