@@ -174,8 +174,10 @@ __global__ __launch_bounds__(kRowThreads) void k_policy_rows(
     }
     return v;
   };
-  // block-wide sums of 2^(x c2 - M) and x 2^(x c2 - M) over the registers
-  auto sums = [&](float M, float& s_out, float& w_out) {
+  // Per-wave sums of 2^(x c2 - M) and x 2^(x c2 - M) over the registers, then merged over the 16 waves.
+  // Every wave uses a reference point M of its own, so no wave waits for another before it starts; the
+  // merge rescales each wave's sums to the largest M.
+  auto sums = [&](float M, float& M_out, float& s_out, float& w_out) {
     float es[4] = {0.0f, 0.0f, 0.0f, 0.0f}, ws[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
@@ -188,36 +190,32 @@ __global__ __launch_bounds__(kRowThreads) void k_policy_rows(
         ws[i & 3] = fmaf(x[i], e, ws[i & 3]);
       }
     }
-    float s = wave_sum((es[0] + es[2]) + (es[1] + es[3]));
-    float w = wave_sum((ws[0] + ws[2]) + (ws[1] + ws[3]));
+    const float s = wave_sum((es[0] + es[2]) + (es[1] + es[3]));
+    const float w = wave_sum((ws[0] + ws[2]) + (ws[1] + ws[3]));
     if (lane == 0) {
+      red_m[wid] = M;
       red_s[wid] = s;
       red_w[wid] = w;
     }
     __syncthreads();
-    s = red_s[0];
-    w = red_w[0];
+    float Mx = red_m[0];
 #pragma unroll
-    for (int i = 1; i < kRowWaves; ++i) {
-      s += red_s[i];
-      w += red_w[i];
+    for (int i = 1; i < kRowWaves; ++i) Mx = fmaxf(Mx, red_m[i]);
+    float st = 0.0f, wt = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kRowWaves; ++i) {
+      const float sc = fast_exp2(red_m[i] - Mx);
+      st = fmaf(red_s[i], sc, st);
+      wt = fmaf(red_w[i], sc, wt);
     }
-    s_out = s;
-    w_out = w;
-  };
-  auto block_max = [&](float mx) -> float {
-    mx = wave_max(mx);
-    if (lane == 0) red_m[wid] = mx;
-    __syncthreads();
-    mx = red_m[0];
-#pragma unroll
-    for (int i = 1; i < kRowWaves; ++i) mx = fmaxf(mx, red_m[i]);
-    return mx;
+    M_out = Mx;
+    s_out = st;
+    w_out = wt;
   };
 
-  // 2. Reference point of the exponentials: the maximum over every lane's first chunk (8192 logits).
+  // 2. Reference point of a wave's exponentials: the maximum over its lanes' first chunks (512 logits).
   //    Any M <= max + ~100/c2 gives the same sums up to rounding; an M so far below the true maximum
-  //    that the sum overflows is caught below and replaced by the exact maximum.
+  //    that a sum overflows is caught below and replaced by the exact maximum of the row.
   float mx = kNegBig;
   {
     float x[8];
@@ -225,14 +223,13 @@ __global__ __launch_bounds__(kRowThreads) void k_policy_rows(
 #pragma unroll
     for (int i = 0; i < 8; ++i) mx = fmaxf(mx, x[i]);
   }
-  float M = block_max(mx) * c2;  // c2 > 0: the largest logit gives the largest scaled logit
+  float M, s, w;
 #if PRL_ROWS_TRACE
-  const uint64_t tick1 = wall_clock64();  // the first chunk has arrived in every wave
+  const uint64_t tick1 = wall_clock64();  // this wave's first chunk has arrived
 #endif
-  float s, w;
-  sums(M, s, w);
+  sums(wave_max(mx) * c2, M, s, w);  // c2 > 0: the largest logit gives the largest scaled logit
 #if PRL_ROWS_TRACE
-  const uint64_t tick2 = wall_clock64();  // all chunks arrived and summed
+  const uint64_t tick2 = wall_clock64();  // all chunks arrived and summed, in every wave
 #endif
   if (!(s <= 3.0e38f) || !(s > 0.0f)) {  // overflow (or a NaN / -inf sample): exact two-pass soft-max
     __syncthreads();                     // every wave has read the first round's sums before they are rewritten
@@ -244,8 +241,14 @@ __global__ __launch_bounds__(kRowThreads) void k_policy_rows(
 #pragma unroll
       for (int i = 0; i < 8; ++i) mx = fmaxf(mx, x[i]);
     }
-    M = block_max(mx) * c2;
-    sums(M, s, w);
+    mx = wave_max(mx);
+    if (lane == 0) red_m[wid] = mx;
+    __syncthreads();
+    mx = red_m[0];
+#pragma unroll
+    for (int i = 1; i < kRowWaves; ++i) mx = fmaxf(mx, red_m[i]);
+    __syncthreads();  // red_m is rewritten by the sums below
+    sums(mx * c2, M, s, w);
   }
 
   // 3. the token's values and its loss gradient (same expressions as the loss kernels, so that the g

@@ -62,13 +62,11 @@ def run(rounds: int = 15, t: int = 2048, v: int = 151936) -> None:
     out = torch.empty(t, v, dtype=torch.bfloat16, device=dev)
     st = C.stream_ptr(dev)
     libs = {}
-    for tag in VARIANTS:
-        path = TUNE / f"librows_{tag}.so"
-        if path.exists():
-            lib = ctypes.CDLL(str(path))
-            fn = lib.prl_policy_rows_fwd_bwd
-            fn.restype, fn.argtypes = C.SIGNATURES["prl_policy_rows_fwd_bwd"]
-            libs[tag] = fn
+    for path in sorted(TUNE.glob("librows_*.so")):  # every build in the directory, also hand-placed ones
+        lib = ctypes.CDLL(str(path))
+        fn = lib.prl_policy_rows_fwd_bwd
+        fn.restype, fn.argtypes = C.SIGNATURES["prl_policy_rows_fwd_bwd"]
+        libs[path.stem[len("librows_"):]] = fn
 
     def call(fn):
         rc = fn(C.ptr(logits), C.PRL_BF16, t, v, v, C.ptr(ids), C.ptr(adv), C.ptr(old), C.ptr(mask), 0, 1.0, 1e30,
@@ -94,7 +92,7 @@ def run(rounds: int = 15, t: int = 2048, v: int = 151936) -> None:
     if "trace" in libs:
         call(libs["trace"])
         torch.cuda.synchronize()
-        for name, arr in (("launch -> first chunk summed", lp), ("rest of the sums pass", ent), ("gradient pass", lse)):
+        for name, arr in (("launch -> first chunk here", lp), ("sums pass and merge", ent), ("gradient pass", lse)):
             x = arr[1:].double() / 100.0
             print(f"trace: {name:30s} mean {x.mean():6.2f} us  min {x.min():6.2f}  max {x.max():6.2f}")
         del libs["trace"], times["trace"]
