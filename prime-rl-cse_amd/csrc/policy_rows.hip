@@ -86,8 +86,9 @@ __device__ __forceinline__ void store_chunk(const u32x4& v, R rsrc, uint32_t vof
 // One workgroup per row.  (Measured alternatives, T = 2048, V = 151936: workgroups that stay on a
 // compute unit and refill each chunk's registers with their next row while the gradient is written
 // were 8 % slower, because loads and stores retire through one in-order counter and the next row's
-// first chunk then waits for this row's stores; pulling a later row towards the caches with one
-// dword per line cost 25 %.)
+// first chunk then waits for this row's stores; workgroups that simply walk over several rows, one
+// or two per compute unit, were no faster than fresh workgroups and cost registers; pulling a later
+// row towards the caches with one dword per line cost 25 %.)
 template <int NCH>
 __global__ __launch_bounds__(kRowThreads) void k_policy_rows(
     const char* __restrict__ logits, int64_t T, int64_t V, int64_t in_stride_bytes, const int64_t* __restrict__ ids,
