@@ -192,9 +192,11 @@ def trainer_measure(dev, world: int, steps: int, warmup: int, cpu: bool, cpu_sec
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    per_step = []
     t0 = time.perf_counter()
     for i in range(steps):
         res = T.train_step(model, opt, batches[i % 2], loss_cfg, device=dev, samples=BATCH)
+        per_step.append(res.seconds)  # train_step ends with the statistics read, a host wait for the whole step
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -206,6 +208,7 @@ def trainer_measure(dev, world: int, steps: int, warmup: int, cpu: bool, cpu_sec
     out = {
         "model": "Qwen3-0.6B (random init, literal dimensions)",
         "ms_per_step": sec * 1e3,
+        "ms_each_step": [round(1e3 * x, 1) for x in per_step],
         "samples_per_s": world * BATCH / sec,
         "tokens_per_s": world * BATCH * SEQ_LEN / sec,
         "mfu_percent_of_2.5PF": 100 * flop / sec / 2.5e15,
@@ -420,7 +423,7 @@ def main() -> None:
             del rows
             torch.cuda.empty_cache()
             try:
-                line["trainer_step"] = trainer_measure(dev, 1, args.trainer_steps, 1, not args.no_cpu_baseline,
+                line["trainer_step"] = trainer_measure(dev, 1, args.trainer_steps, 2, not args.no_cpu_baseline,
                                                        args.cpu_seconds)
             except Exception as exc:  # the headline line must not depend on the transformers install
                 line["trainer_step"] = {"error": f"{type(exc).__name__}: {exc}"}

@@ -76,17 +76,33 @@ def get_model(cfg: Any, device: torch.device | str, dtype: torch.dtype = torch.f
     return model
 
 
+def blocks_per_fsdp_group(model: nn.Module, target_bytes: int = 1 << 30) -> int:
+    """How many transformer blocks share one FSDP group so that a group's bf16 parameters come to about
+    `target_bytes`.  The reference makes one group per block (src/prime_rl/trainer/model.py:106-113), sized
+    for 80 GB parts; with 288 GB of HBM per GPU and point-to-point xGMI links, fewer and larger all-gathers /
+    reduce-scatters use the links better and cost the host fewer hooks: Qwen3-0.6B (31 MB per block) becomes
+    one group of 28 blocks, a 7B model two blocks per group, a 32B model one."""
+    blocks = list(model.model.layers)
+    per_block = sum(p.numel() for p in blocks[0].parameters()) * 2
+    return max(1, min(len(blocks), target_bytes // max(per_block, 1)))
+
+
 def setup_fsdp(model: nn.Module, mesh: Any, reduce_dtype: torch.dtype = torch.float32,
-               reshard_after_forward: bool = True) -> nn.Module:
-    """FSDP2 over a 1-D data-parallel mesh, grouped as the reference groups it
-    (src/prime_rl/trainer/model.py:102-135): one group per transformer block,
-    bf16 parameters on the wire, fp32 gradient reduction; for untied models the
-    embedding and [lm_head, final norm] get groups of their own."""
+               reshard_after_forward: bool = True, blocks_per_group: int | None = None) -> nn.Module:
+    """FSDP2 over a 1-D data-parallel mesh as the reference sets it up
+    (src/prime_rl/trainer/model.py:102-135): bf16 parameters on the wire, fp32
+    gradient reduction, transformer blocks in groups (`blocks_per_group`, default
+    `blocks_per_fsdp_group`; 1 reproduces the reference's one group per block);
+    for untied models the embedding and [lm_head, final norm] get groups of their own."""
     from torch.distributed.fsdp import MixedPrecisionPolicy, fully_shard
 
     mp = MixedPrecisionPolicy(param_dtype=torch.bfloat16, reduce_dtype=reduce_dtype)
-    for block in model.model.layers:
-        fully_shard(block, mesh=mesh, mp_policy=mp, reshard_after_forward=reshard_after_forward)
+    blocks = list(model.model.layers)
+    per = blocks_per_group if blocks_per_group else blocks_per_fsdp_group(model)
+    for a in range(0, len(blocks), per):
+        group = blocks[a : a + per]
+        fully_shard(group if len(group) > 1 else group[0], mesh=mesh, mp_policy=mp,
+                    reshard_after_forward=reshard_after_forward)
     if not model.config.tie_word_embeddings:
         fully_shard(model.model.embed_tokens, mesh=mesh, mp_policy=mp, reshard_after_forward=reshard_after_forward)
         fully_shard([model.lm_head, model.model.norm], mesh=mesh, mp_policy=mp, reshard_after_forward=False)
