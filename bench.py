@@ -62,6 +62,9 @@ def parse() -> argparse.Namespace:
     p.add_argument("--no-trainer-extra", action="store_true",
                    help="at --gpus 1, do not append the short whole-trainer-step measurement to the line")
     p.add_argument("--trainer-steps", type=int, default=3)
+    p.add_argument("--trainer-impl", choices=["hf", "fused"], default="fused",
+                   help="whole-trainer-step workload: hf = the transformers blocks as they are; fused = their "
+                        "RMSNorm modules on this package's HIP kernels (the reference's model.impl = liger_kernel)")
     return p.parse_args()
 
 
@@ -166,7 +169,8 @@ def pmc_traffic(kernel: str, logits_dtype: str) -> tuple[float | None, str | Non
     return best if best else (None, None)
 
 
-def trainer_measure(dev, world: int, steps: int, warmup: int, cpu: bool, cpu_seconds: float) -> dict:
+def trainer_measure(dev, world: int, steps: int, warmup: int, cpu: bool, cpu_seconds: float,
+                    impl: str = "fused") -> dict:
     """The whole optimizer step of the Qwen3-0.6B reverse_text recipe on synthetic rollouts: transformer body by
     PyTorch-ROCm (random init, bf16 compute under FSDP2, fp32 master weights and gradient reduction), everything
     after the LM head by this package, gradient clipping and AdamW (src/prime_rl/trainer/rl/train.py:259-352)."""
@@ -180,6 +184,11 @@ def trainer_measure(dev, world: int, steps: int, warmup: int, cpu: bool, cpu_sec
     mesh = T.init_distributed(dev)
     cfg = T.model_config("Qwen/Qwen3-0.6B")
     model = T.get_model(cfg, dev, torch.float32, seed=0)
+    fused_modules = {}
+    if impl == "fused":
+        from prime_rl_cse_amd import fused
+
+        fused_modules = fused.fuse_model(model)
     T.setup_fsdp(model, mesh)
     opt = T.setup_optimizer(model)
     prl.reset_world()
@@ -217,6 +226,8 @@ def trainer_measure(dev, world: int, steps: int, warmup: int, cpu: bool, cpu_sec
         "grad_norm": res.grad_norm,
         "precision": "bf16 compute, fp32 master weights and gradient reduction (FSDP2 mixed precision), fp32 loss math",
         "attention": "sdpa",
+        "blocks": "transformers Qwen3" + (f", modules on HIP kernels: {fused_modules}" if fused_modules else ""),
+        "fsdp_blocks_per_group": T.blocks_per_fsdp_group(model),
     }
     del model, opt
     torch.cuda.empty_cache()
@@ -284,7 +295,8 @@ def main() -> None:
     from prime_rl_cse_amd import _capi, perf  # noqa: F401
 
     if args.workload == "trainer":
-        info = trainer_measure(dev, world, args.steps, args.warmup, not args.no_cpu_baseline, args.cpu_seconds)
+        info = trainer_measure(dev, world, args.steps, args.warmup, not args.no_cpu_baseline, args.cpu_seconds,
+                               args.trainer_impl)
         if rank == 0:
             line = {"metric": "policy_update_samples_per_sec", "value": info["samples_per_s"], "unit": "samples/s",
                     "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": info["ms_per_step"],
@@ -424,7 +436,7 @@ def main() -> None:
             torch.cuda.empty_cache()
             try:
                 line["trainer_step"] = trainer_measure(dev, 1, args.trainer_steps, 2, not args.no_cpu_baseline,
-                                                       args.cpu_seconds)
+                                                       args.cpu_seconds, args.trainer_impl)
             except Exception as exc:  # the headline line must not depend on the transformers install
                 line["trainer_step"] = {"error": f"{type(exc).__name__}: {exc}"}
         print(json.dumps(line), flush=True)

@@ -211,6 +211,46 @@ int prl_scale_rows_if_not_one(void* x, int dtype, int64_t T, int64_t V, int64_t 
                               void* stream);
 
 /*
+ * RMSNorm over the rows of a [rows, H] activation, forward and backward:
+ *   y = w * cast(x32 * rsqrt(mean(x32^2) + eps)),  x32 = float(x), cast to the dtype of x,
+ * the arithmetic of the normalisation module in the transformer blocks the
+ * trainer runs.  Counterpart of the fused kernels the reference switches on
+ * with `model.impl = "liger_kernel"` (src/prime_rl/trainer/model.py:74-75,
+ * src/prime_rl/trainer/config.py:179-184).  x, y, gy, gx and w share `dtype`
+ * (bf16 or fp32); rstd (fp32 [rows]) is written by the forward for the
+ * backward; gw receives the weight gradient summed over the rows in a fixed
+ * order.  Row strides in elements; pointers and strides 16-byte aligned, H a
+ * multiple of 8 (bf16) or 4 (fp32); prl_rmsnorm_supported says whether a row
+ * length is handled.  The backward needs prl_rmsnorm_bwd_workspace_bytes of
+ * caller scratch.
+ */
+int prl_rmsnorm_supported(int dtype, int64_t H);
+size_t prl_rmsnorm_bwd_workspace_bytes(int dtype, int64_t rows, int64_t H);
+int prl_rmsnorm_fwd(const void* x, int64_t x_row_stride, const void* w, void* y, int64_t y_row_stride, float* rstd,
+                    int dtype, int64_t rows, int64_t H, float eps, void* stream);
+int prl_rmsnorm_bwd(const void* x, int64_t x_row_stride, const void* w, const float* rstd, const void* gy,
+                    int64_t gy_row_stride, void* gx, int64_t gx_row_stride, void* gw, int dtype, int64_t rows,
+                    int64_t H, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Rotary position embedding of query and key in one launch:
+ *   out = x * cos + rotate_half(x) * sin   over the last dimension D,
+ * or, with inverse = 1, the transpose of that map (the backward applied to the
+ * incoming gradients).  Same switch in the reference as prl_rmsnorm_*
+ * (`model.impl = "liger_kernel"`, src/prime_rl/trainer/model.py:74-75); the
+ * arithmetic is transformers' apply_rotary_pos_emb.  q is [B, q_heads, T, D],
+ * k is [B, k_heads, T, D], any strides with a contiguous last dimension:
+ * q_strides / k_strides are HOST arrays of 6 element strides (batch, head,
+ * token of the input, then of the output).  cos, sin are [B, T, D] with the
+ * given batch and token strides.  Everything 16-byte aligned; D a multiple of
+ * 16 (bf16) or 8 (fp32) (prl_rope_supported).
+ */
+int prl_rope_supported(int dtype, int64_t D);
+int prl_rope(const void* q, void* q_out, const int64_t* q_strides, int64_t q_heads, const void* k, void* k_out,
+             const int64_t* k_strides, int64_t k_heads, const void* cos_, const void* sin_, int64_t cs_batch_stride,
+             int64_t cs_token_stride, int dtype, int64_t B, int64_t T, int64_t D, int inverse, void* stream);
+
+/*
  * Group-relative advantages: B rewards in consecutive groups of G.  Replaces
  * compute_advantages (src/prime_rl/orchestrator/advantage.py:71-103) for the
  * four kinds of its REGISTRY (:63-68).  `lengths` (int64 [B], completion

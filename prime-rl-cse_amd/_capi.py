@@ -68,6 +68,23 @@ SIGNATURES = {
          c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p],
     ),
     "prl_scale_rows_if_not_one": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
+    "prl_rope_supported": (c_int, [c_int, c_int64]),
+    "prl_rope": (
+        c_int,
+        [c_void_p, c_void_p, POINTER(c_int64), c_int64, c_void_p, c_void_p, POINTER(c_int64), c_int64, c_void_p,
+         c_void_p, c_int64, c_int64, c_int, c_int64, c_int64, c_int64, c_int, c_void_p],
+    ),
+    "prl_rmsnorm_supported": (c_int, [c_int, c_int64]),
+    "prl_rmsnorm_bwd_workspace_bytes": (c_size_t, [c_int, c_int64, c_int64]),
+    "prl_rmsnorm_fwd": (
+        c_int,
+        [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int64, c_int64, c_float, c_void_p],
+    ),
+    "prl_rmsnorm_bwd": (
+        c_int,
+        [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int64,
+         c_int64, c_void_p, c_size_t, c_void_p],
+    ),
     "prl_group_advantage": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "prl_stats_workspace_bytes": (c_size_t, [c_int]),
     "prl_stats_layout": (c_int, [c_int, POINTER(c_int64)]),

@@ -1,0 +1,397 @@
+// RMSNorm forward and backward over rows of a [rows, H] activation, one launch each
+// (plus a small column-sum finish for the weight gradient).
+//
+// The transformer blocks the trainer runs (src/prime_rl/trainer/model.py:71-88 loads
+// them from transformers) spell the normalisation as seven element-wise and reduction
+// kernels forward and about fifteen backward, 113 times per micro-batch for a 28-layer
+// Qwen3 (input, post-attention, query and key norms); at T = 2048 every one of them is
+// a 4-7 us launch.  The reference's own switch for this is `model.impl = "liger_kernel"`
+// (src/prime_rl/trainer/model.py:74-75, Triton kernels); this is that switch's counterpart
+// here.  Arithmetic follows the module being replaced:
+//     y = w * cast(x32 * rsqrt(mean(x32^2) + eps))        x32 = float(x), cast to x's dtype
+// HBM-bound: x read once, y written once forward; x, gy read and gx written backward.
+#include "logprob_dev.h"
+
+namespace prl {
+
+constexpr int kNormThreads = 256;
+constexpr int kNormMaxBlocks = 128;  // also the number of partial rows the weight-gradient finish adds up
+
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, LPR);
+  return v;
+}
+
+__device__ __forceinline__ float round_to(float v, int dt) { return dt == PRL_BF16 ? bf16_one(one_bf16(v)) : v; }
+
+template <int DT>
+__device__ __forceinline__ void load_vec(const char* p, int64_t v, float* out) {
+  u32x4 raw = reinterpret_cast<const u32x4*>(p)[v];
+  decode16_raw<DT>(raw, out);
+}
+
+// LPR lanes share a row (16 for short rows such as a 128-wide head, 64 otherwise); a lane owns the
+// 16-byte vectors li, li + LPR, ... of its row, NV of them at most.
+template <int DT, int LPR, int NV>
+__global__ __launch_bounds__(kNormThreads) void k_rmsnorm_fwd(const char* __restrict__ x, int64_t x_stride,
+                                                              const char* __restrict__ w, char* __restrict__ y,
+                                                              int64_t y_stride, float* __restrict__ rstd,
+                                                              int64_t rows, int H, float eps) {
+  constexpr int VE = DT == PRL_F32 ? 4 : 8;
+  constexpr int RPB = kNormThreads / LPR;  // rows per workgroup and step
+  const int li = threadIdx.x % LPR, slot = threadIdx.x / LPR;
+  const int nvec = H / VE;
+  float wv[NV][VE];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int v = li + k * LPR;
+    if (v < nvec) load_vec<DT>(w, v, wv[k]);
+  }
+  for (int64_t row = (int64_t)blockIdx.x * RPB + slot; row < rows; row += (int64_t)gridDim.x * RPB) {
+    const char* xp = x + row * x_stride;
+    float xv[NV][VE];
+    float ss = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int v = li + k * LPR;
+      if (v < nvec) {
+        load_vec<DT>(xp, v, xv[k]);
+#pragma unroll
+        for (int i = 0; i < VE; ++i) ss = fmaf(xv[k][i], xv[k][i], ss);
+      }
+    }
+    ss = row_sum<LPR>(ss);
+    const float rs = rsqrtf(ss / (float)H + eps);
+    if (li == 0 && rstd) rstd[row] = rs;
+    char* yp = y + row * y_stride;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int v = li + k * LPR;
+      if (v < nvec) {
+        float o[VE];
+#pragma unroll
+        for (int i = 0; i < VE; ++i) o[i] = wv[k][i] * round_to(xv[k][i] * rs, DT);
+        store_unit<DT, VE>(yp, v, o);
+      }
+    }
+  }
+}
+
+// gx = rstd * (gy w - xh * mean(gy w xh)),  xh = x * rstd;  per-workgroup column sums of gy * cast(xh)
+// go to gw_part[blockIdx.x, :].
+template <int DT, int LPR, int NV>
+__global__ __launch_bounds__(kNormThreads) void k_rmsnorm_bwd(const char* __restrict__ x, int64_t x_stride,
+                                                              const char* __restrict__ w,
+                                                              const float* __restrict__ rstd,
+                                                              const char* __restrict__ gy, int64_t gy_stride,
+                                                              char* __restrict__ gx, int64_t gx_stride,
+                                                              float* __restrict__ gw_part, int64_t rows, int H) {
+  constexpr int VE = DT == PRL_F32 ? 4 : 8;
+  constexpr int RPB = kNormThreads / LPR;
+  extern __shared__ float lds[];  // RPB * H floats: the row slots' column sums
+  const int li = threadIdx.x % LPR, slot = threadIdx.x / LPR;
+  const int nvec = H / VE;
+  const float inv_h = 1.0f / (float)H;
+  float wv[NV][VE], acc[NV][VE];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int v = li + k * LPR;
+    if (v < nvec) load_vec<DT>(w, v, wv[k]);
+#pragma unroll
+    for (int i = 0; i < VE; ++i) acc[k][i] = 0.0f;
+  }
+  for (int64_t row = (int64_t)blockIdx.x * RPB + slot; row < rows; row += (int64_t)gridDim.x * RPB) {
+    const char* xp = x + row * x_stride;
+    const char* gp = gy + row * gy_stride;
+    const float rs = rstd[row];
+    float xh[NV][VE], gw_[NV][VE];
+    float dot = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int v = li + k * LPR;
+      if (v < nvec) {
+        float g[VE];
+        load_vec<DT>(xp, v, xh[k]);
+        load_vec<DT>(gp, v, g);
+#pragma unroll
+        for (int i = 0; i < VE; ++i) {
+          xh[k][i] *= rs;
+          acc[k][i] = fmaf(g[i], round_to(xh[k][i], DT), acc[k][i]);
+          gw_[k][i] = g[i] * wv[k][i];
+          dot = fmaf(gw_[k][i], xh[k][i], dot);
+        }
+      }
+    }
+    dot = row_sum<LPR>(dot) * inv_h;
+    char* op = gx + row * gx_stride;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int v = li + k * LPR;
+      if (v < nvec) {
+        float o[VE];
+#pragma unroll
+        for (int i = 0; i < VE; ++i) o[i] = rs * (gw_[k][i] - xh[k][i] * dot);
+        store_unit<DT, VE>(op, v, o);
+      }
+    }
+  }
+  // column sums: row slots -> LDS -> one row per workgroup
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int v = li + k * LPR;
+    if (v < nvec) {
+#pragma unroll
+      for (int i = 0; i < VE; ++i) lds[slot * H + v * VE + i] = acc[k][i];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < H; c += kNormThreads) {
+    float s = 0.0f;
+#pragma unroll
+    for (int r = 0; r < RPB; ++r) s += lds[r * H + c];
+    gw_part[(int64_t)blockIdx.x * H + c] = s;
+  }
+}
+
+// out[c] = sum over the partial rows of part[p, c], in a fixed order.  A workgroup owns 32 columns; its
+// 8 groups of 32 threads each take every 8th partial row (loads of 128 contiguous bytes), then the
+// groups' sums are added through LDS.
+template <int DT>
+__global__ __launch_bounds__(256) void k_colsum_finish(const float* __restrict__ part, int nparts, int H,
+                                                       char* __restrict__ out) {
+  __shared__ float lds[8][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
+  float s = 0.0f;
+  if (c < H)
+    for (int p = g; p < nparts; p += 8) s += part[(int64_t)p * H + c];
+  lds[g][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (g == 0 && c < H) {
+    float t = lds[0][threadIdx.x];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += lds[k][threadIdx.x];
+    store_elem<DT>(out, c, t);
+  }
+}
+
+static int norm_blocks(int64_t rows, int lpr) {
+  const int64_t rpb = kNormThreads / lpr;
+  const int64_t want = (rows + rpb - 1) / rpb;
+  return (int)(want < kNormMaxBlocks ? (want > 0 ? want : 1) : kNormMaxBlocks);
+}
+static int norm_lpr(int64_t H, int ve) { return H / ve <= 16 ? 16 : 64; }
+static int norm_nv(int64_t H, int ve, int lpr) { return (int)((H / ve + lpr - 1) / lpr); }
+
+}  // namespace prl
+
+using namespace prl;
+
+extern "C" int prl_rmsnorm_supported(int dtype, int64_t H) {
+  if (dtype != PRL_F32 && dtype != PRL_BF16) return 0;
+  const int ve = dtype == PRL_F32 ? 4 : 8;
+  if (H < ve || H % ve) return 0;
+  const int lpr = norm_lpr(H, ve);
+  return norm_nv(H, ve, lpr) <= 16 && H * (int64_t)(kNormThreads / lpr) * 4 <= 64 * 1024 ? 1 : 0;
+}
+
+extern "C" size_t prl_rmsnorm_bwd_workspace_bytes(int dtype, int64_t rows, int64_t H) {
+  const int ve = dtype == PRL_F32 ? 4 : 8;
+  return (size_t)norm_blocks(rows, norm_lpr(H, ve)) * (size_t)H * sizeof(float);
+}
+
+#define PRL_NORM_DISPATCH(KERNEL, ...)                                    \
+  do {                                                                    \
+    if (dtype == PRL_BF16) {                                              \
+      if (lpr == 16) KERNEL(PRL_BF16, 16, 1, __VA_ARGS__);                \
+      else if (nv <= 1) KERNEL(PRL_BF16, 64, 1, __VA_ARGS__);             \
+      else if (nv <= 2) KERNEL(PRL_BF16, 64, 2, __VA_ARGS__);             \
+      else if (nv <= 4) KERNEL(PRL_BF16, 64, 4, __VA_ARGS__);             \
+      else if (nv <= 8) KERNEL(PRL_BF16, 64, 8, __VA_ARGS__);             \
+      else KERNEL(PRL_BF16, 64, 16, __VA_ARGS__);                         \
+    } else {                                                              \
+      if (lpr == 16) KERNEL(PRL_F32, 16, 1, __VA_ARGS__);                 \
+      else if (nv <= 1) KERNEL(PRL_F32, 64, 1, __VA_ARGS__);              \
+      else if (nv <= 2) KERNEL(PRL_F32, 64, 2, __VA_ARGS__);              \
+      else if (nv <= 4) KERNEL(PRL_F32, 64, 4, __VA_ARGS__);              \
+      else if (nv <= 8) KERNEL(PRL_F32, 64, 8, __VA_ARGS__);              \
+      else KERNEL(PRL_F32, 64, 16, __VA_ARGS__);                          \
+    }                                                                     \
+  } while (0)
+
+static int norm_check(const char* who, int dtype, int64_t rows, int64_t H, const void* a, const void* b, const void* c,
+                      int64_t s0, int64_t s1) {
+  PRL_REQUIRE(rows >= 0, "%s: rows must be >= 0", who);
+  PRL_REQUIRE(prl_rmsnorm_supported(dtype, H), "%s: unsupported dtype %d or row length %lld", who, dtype, (long long)H);
+  PRL_REQUIRE(s0 >= H && s1 >= H, "%s: row strides must be >= H", who);
+  const int es = dtype == PRL_F32 ? 4 : 2;
+  PRL_REQUIRE(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
+                (uintptr_t)(s0 * es) | (uintptr_t)(s1 * es)) & 15) == 0,
+              "%s: pointers and row strides must be 16-byte aligned", who);
+  return PRL_OK;
+}
+
+extern "C" int prl_rmsnorm_fwd(const void* x, int64_t x_row_stride, const void* w, void* y, int64_t y_row_stride,
+                               float* rstd, int dtype, int64_t rows, int64_t H, float eps, void* stream) {
+  clear_error();
+  int rc = norm_check("rmsnorm_fwd", dtype, rows, H, x, w, y, x_row_stride, y_row_stride);
+  if (rc != PRL_OK) return rc;
+  if (rows == 0) return PRL_OK;
+  PRL_REQUIRE(x && w && y, "rmsnorm_fwd: x, w and y must not be NULL");
+  const int es = dtype == PRL_F32 ? 4 : 2, ve = 16 / es;
+  const int lpr = norm_lpr(H, ve), nv = norm_nv(H, ve, lpr);
+  const dim3 grid((unsigned)norm_blocks(rows, lpr)), block(kNormThreads);
+  hipStream_t st = (hipStream_t)stream;
+#define PRL_FWD(DT, L, N, ...)                                                                                     \
+  hipLaunchKernelGGL((k_rmsnorm_fwd<DT, L, N>), grid, block, 0, st, (const char*)x, x_row_stride * es, (const char*)w, \
+                     (char*)y, y_row_stride * es, rstd, rows, (int)H, eps)
+  PRL_NORM_DISPATCH(PRL_FWD, 0);
+#undef PRL_FWD
+  PRL_CHECK_LAUNCH("rmsnorm_fwd");
+  return PRL_OK;
+}
+
+extern "C" int prl_rmsnorm_bwd(const void* x, int64_t x_row_stride, const void* w, const float* rstd, const void* gy,
+                               int64_t gy_row_stride, void* gx, int64_t gx_row_stride, void* gw, int dtype,
+                               int64_t rows, int64_t H, void* workspace, size_t workspace_bytes, void* stream) {
+  clear_error();
+  int rc = norm_check("rmsnorm_bwd", dtype, rows, H, x, gy, gx, x_row_stride, gy_row_stride);
+  if (rc != PRL_OK) return rc;
+  PRL_REQUIRE(gx_row_stride >= H && ((gx_row_stride * (dtype == PRL_F32 ? 4 : 2)) & 15) == 0,
+              "rmsnorm_bwd: gx row stride must be >= H and 16-byte aligned");
+  PRL_REQUIRE(x && w && rstd && gy && gx && gw, "rmsnorm_bwd: x, w, rstd, gy, gx and gw must not be NULL");
+  PRL_REQUIRE((reinterpret_cast<uintptr_t>(w) & 15) == 0, "rmsnorm_bwd: w must be 16-byte aligned");
+  const int es = dtype == PRL_F32 ? 4 : 2, ve = 16 / es;
+  const int lpr = norm_lpr(H, ve), nv = norm_nv(H, ve, lpr);
+  const int nblk = norm_blocks(rows, lpr);
+  PRL_REQUIRE(workspace && workspace_bytes >= (size_t)nblk * H * sizeof(float),
+              "rmsnorm_bwd: workspace of %zu bytes needed (prl_rmsnorm_bwd_workspace_bytes)",
+              (size_t)nblk * H * sizeof(float));
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  const dim3 grid((unsigned)nblk), block(kNormThreads);
+  const size_t lds = (size_t)(kNormThreads / lpr) * H * sizeof(float);
+#define PRL_BWD(DT, L, N, ...)                                                                                      \
+  hipLaunchKernelGGL((k_rmsnorm_bwd<DT, L, N>), grid, block, lds, st, (const char*)x, x_row_stride * es, (const char*)w, \
+                     rstd, (const char*)gy, gy_row_stride * es, (char*)gx, gx_row_stride * es, part, rows, (int)H)
+  PRL_NORM_DISPATCH(PRL_BWD, 0);
+#undef PRL_BWD
+  PRL_CHECK_LAUNCH("rmsnorm_bwd");
+  const dim3 fgrid((unsigned)((H + 31) / 32));
+  if (dtype == PRL_BF16)
+    hipLaunchKernelGGL((k_colsum_finish<PRL_BF16>), fgrid, dim3(256), 0, st, part, nblk, (int)H, (char*)gw);
+  else
+    hipLaunchKernelGGL((k_colsum_finish<PRL_F32>), fgrid, dim3(256), 0, st, part, nblk, (int)H, (char*)gw);
+  PRL_CHECK_LAUNCH("rmsnorm_bwd(finish)");
+  return PRL_OK;
+}
+
+// ---------------------------------------------------------------- rotary position embedding
+//
+// out = x * cos + rotate_half(x) * sin over the last dimension D of query and key, both in one launch:
+//   out[i]       = x[i] cos[i]             - x[i + D/2] sin[i]              i <  D/2
+//   out[i + D/2] = x[i + D/2] cos[i + D/2] + x[i] sin[i + D/2]
+// and, with `inverse`, the transpose of that map (what the backward applies to the incoming gradient).
+// The transformers blocks spell it as ~14 small kernels forward and ~20 backward per layer
+// (slices, negation, concatenation, four products, two sums); the reference's switch for a fused
+// version is again `model.impl = "liger_kernel"` (src/prime_rl/trainer/model.py:74-75).
+namespace prl {
+
+struct RopeTensor {
+  const char* x;
+  char* out;
+  int64_t xb, xh, xt;  // element strides of batch, head, token in x (the last dimension is contiguous)
+  int64_t ob, oh, ot;  // the same for out
+  int64_t heads;
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_rope(RopeTensor q, RopeTensor k, const char* __restrict__ cs,
+                                              const char* __restrict__ sn, int64_t cb, int64_t ct, int64_t B,
+                                              int64_t T, int D, int inverse) {
+  constexpr int ES = DT == PRL_F32 ? 4 : 2;
+  constexpr int VE = 16 / ES;
+  const int lpr = D / (2 * VE);  // lanes per row: each owns one 16-byte vector of either half
+  const int rpb = 256 / lpr;
+  const int li = threadIdx.x % lpr, slot = threadIdx.x / lpr;
+  if (slot >= rpb) return;
+  const int64_t qrows = B * q.heads * T, rows = qrows + B * k.heads * T;
+  for (int64_t r = (int64_t)blockIdx.x * rpb + slot; r < rows; r += (int64_t)gridDim.x * rpb) {
+    const RopeTensor& a = r < qrows ? q : k;
+    int64_t i = r < qrows ? r : r - qrows;
+    // row order (batch, token, head): neighbouring rows share cos / sin and, in the usual layout, memory
+    const int64_t h = i % a.heads;
+    i /= a.heads;
+    const int64_t t = i % T, b = i / T;
+    const char* xp = a.x + (b * a.xb + h * a.xh + t * a.xt) * ES;
+    char* op = a.out + (b * a.ob + h * a.oh + t * a.ot) * ES;
+    const char* cp = cs + (b * cb + t * ct) * ES;
+    const char* sp = sn + (b * cb + t * ct) * ES;
+    float x1[VE], x2[VE], c1[VE], c2[VE], s1[VE], s2[VE], o1[VE], o2[VE];
+    load_vec<DT>(xp, li, x1);
+    load_vec<DT>(xp, li + lpr, x2);
+    load_vec<DT>(cp, li, c1);
+    load_vec<DT>(cp, li + lpr, c2);
+    load_vec<DT>(sp, li, s1);
+    load_vec<DT>(sp, li + lpr, s2);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      if (!inverse) {
+        o1[e] = fmaf(x1[e], c1[e], -(x2[e] * s1[e]));
+        o2[e] = fmaf(x2[e], c2[e], x1[e] * s2[e]);
+      } else {
+        o1[e] = fmaf(x1[e], c1[e], x2[e] * s2[e]);
+        o2[e] = fmaf(x2[e], c2[e], -(x1[e] * s1[e]));
+      }
+    }
+    store_unit<DT, VE>(op, li, o1);
+    store_unit<DT, VE>(op, li + lpr, o2);
+  }
+}
+
+}  // namespace prl
+
+extern "C" int prl_rope_supported(int dtype, int64_t D) {
+  if (dtype != PRL_F32 && dtype != PRL_BF16) return 0;
+  const int ve = dtype == PRL_F32 ? 4 : 8;
+  return D >= 2 * ve && D % (2 * ve) == 0 && D / (2 * ve) <= 256 && 256 % (D / (2 * ve)) == 0 ? 1 : 0;
+}
+
+extern "C" int prl_rope(const void* q, void* q_out, const int64_t* q_strides, int64_t q_heads, const void* k, void* k_out,
+                        const int64_t* k_strides, int64_t k_heads, const void* cos_, const void* sin_,
+                        int64_t cs_batch_stride, int64_t cs_token_stride, int dtype, int64_t B, int64_t T, int64_t D,
+                        int inverse, void* stream) {
+  clear_error();
+  PRL_REQUIRE(B >= 0 && T >= 0 && q_heads >= 0 && k_heads >= 0, "rope: sizes must be >= 0");
+  PRL_REQUIRE(prl_rope_supported(dtype, D), "rope: unsupported dtype %d or head size %lld", dtype, (long long)D);
+  if (B * T * (q_heads + k_heads) == 0) return PRL_OK;
+  PRL_REQUIRE(q && q_out && k && k_out && cos_ && sin_ && q_strides && k_strides,
+              "rope: tensors and stride arrays (host, 6 entries: batch, head, token of the input, then of the output) "
+              "must not be NULL");
+  const int es = dtype == PRL_F32 ? 4 : 2;
+  uintptr_t bits = reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(q_out) | reinterpret_cast<uintptr_t>(k) |
+                   reinterpret_cast<uintptr_t>(k_out) | reinterpret_cast<uintptr_t>(cos_) |
+                   reinterpret_cast<uintptr_t>(sin_) | (uintptr_t)(cs_batch_stride * es) |
+                   (uintptr_t)(cs_token_stride * es);
+  for (int i = 0; i < 6; ++i) bits |= (uintptr_t)(q_strides[i] * es) | (uintptr_t)(k_strides[i] * es);
+  PRL_REQUIRE((bits & 15) == 0, "rope: pointers and strides must be 16-byte aligned");
+  prl::RopeTensor tq = {(const char*)q, (char*)q_out, q_strides[0], q_strides[1], q_strides[2],
+                        q_strides[3],   q_strides[4], q_strides[5], q_heads};
+  prl::RopeTensor tk = {(const char*)k, (char*)k_out, k_strides[0], k_strides[1], k_strides[2],
+                        k_strides[3],   k_strides[4], k_strides[5], k_heads};
+  const int ve = 16 / es;
+  const int64_t rpb = 256 / (D / (2 * ve));
+  const int64_t rows = B * T * (q_heads + k_heads);
+  int64_t nblk = (rows + rpb - 1) / rpb;
+  if (nblk > 4096) nblk = 4096;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == PRL_BF16)
+    hipLaunchKernelGGL((prl::k_rope<PRL_BF16>), dim3((unsigned)nblk), dim3(256), 0, st, tq, tk, (const char*)cos_,
+                       (const char*)sin_, cs_batch_stride, cs_token_stride, B, T, (int)D, inverse ? 1 : 0);
+  else
+    hipLaunchKernelGGL((prl::k_rope<PRL_F32>), dim3((unsigned)nblk), dim3(256), 0, st, tq, tk, (const char*)cos_,
+                       (const char*)sin_, cs_batch_stride, cs_token_stride, B, T, (int)D, inverse ? 1 : 0);
+  PRL_CHECK_LAUNCH("rope");
+  return PRL_OK;
+}

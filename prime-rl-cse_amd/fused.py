@@ -1,0 +1,212 @@
+"""Fused HIP kernels for the transformer blocks, switched on per model.
+
+The reference's switch is `model.impl = "liger_kernel"`, which swaps Triton
+kernels for RMSNorm, RoPE and SwiGLU into the HF model
+(src/prime_rl/trainer/model.py:74-75, src/prime_rl/trainer/config.py:179-184).
+`fuse_model(model)` is that switch here: it rebinds the `forward` of the
+model's normalisation modules to `rms_norm` (one HIP launch forward and two
+backward instead of ~22 small torch kernels) and the model family's
+`apply_rotary_pos_emb` to one launch for query and key together (instead of
+~14 forward and ~20 backward).  Modules whose shape or dtype the
+kernels do not cover keep their torch forward (on the same device; nothing
+moves to the host).
+"""
+
+from __future__ import annotations
+
+import types
+from typing import Any
+
+import torch
+from torch import Tensor, nn
+
+from . import _capi as C
+
+
+class _RMSNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, weight: Tensor, eps: float):
+        dev = C.require_device(x, weight)
+        lib = C.load()
+        h = x.shape[-1]
+        x2 = x.reshape(-1, h)  # a view whenever the leading dimensions are laid out evenly; else one copy
+        if x2.stride(-1) != 1:
+            x2 = x2.contiguous()
+        rows = x2.shape[0]
+        w = weight.contiguous()
+        y = torch.empty((rows, h), dtype=x.dtype, device=dev)
+        rstd = torch.empty(rows, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev), C.timed("prl_rmsnorm_fwd", dev):
+            C.check(
+                lib.prl_rmsnorm_fwd(C.ptr(x2), x2.stride(0) if rows > 1 else h, C.ptr(w), C.ptr(y), h, C.ptr(rstd),
+                                    C.dtype_code(x), rows, h, eps, C.stream_ptr(dev)),
+                "prl_rmsnorm_fwd",
+            )
+        ctx.save_for_backward(x2, w, rstd)
+        ctx.shape = x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        x2, w, rstd = ctx.saved_tensors
+        dev = x2.device
+        lib = C.load()
+        rows, h = x2.shape
+        g2 = gy.reshape(rows, h)
+        if g2.stride(-1) != 1 or (rows > 1 and (g2.stride(0) * g2.element_size()) % 16) or g2.data_ptr() % 16:
+            g2 = g2.contiguous()
+        gx = torch.empty((rows, h), dtype=x2.dtype, device=dev)
+        gw = torch.empty(h, dtype=w.dtype, device=dev)
+        code = C.dtype_code(x2)
+        ws_bytes = lib.prl_rmsnorm_bwd_workspace_bytes(code, rows, h)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev), C.timed("prl_rmsnorm_bwd", dev):
+            C.check(
+                lib.prl_rmsnorm_bwd(C.ptr(x2), x2.stride(0) if rows > 1 else h, C.ptr(w), C.ptr(rstd), C.ptr(g2),
+                                    g2.stride(0) if rows > 1 else h, C.ptr(gx), h, C.ptr(gw), code, rows, h,
+                                    C.ptr(ws), ws_bytes, C.stream_ptr(dev)),
+                "prl_rmsnorm_bwd",
+            )
+        return gx.view(ctx.shape), gw, None
+
+
+def rms_norm_supported(x: Tensor, weight: Tensor) -> bool:
+    """Whether `rms_norm` takes these tensors: same dtype (bf16 or fp32), on a HIP device, rows 16-byte aligned."""
+    if not (x.is_cuda and weight.is_cuda) or x.dtype != weight.dtype or x.dtype not in (torch.bfloat16, torch.float32):
+        return False
+    h = x.shape[-1]
+    if weight.shape != (h,) or x.numel() == 0:
+        return False
+    es = x.element_size()
+    if (h * es) % 16 or x.data_ptr() % 16 or weight.data_ptr() % 16 or x.stride(-1) != 1:
+        return False
+    if x.ndim >= 2 and x.shape[:-1].numel() > 1 and any((s * es) % 16 for s in x.stride()[:-1]):
+        return False
+    return bool(C.load().prl_rmsnorm_supported(C.dtype_code(x), h))
+
+
+def rms_norm(x: Tensor, weight: Tensor, eps: float) -> Tensor:
+    """y = weight * cast(float(x) * rsqrt(mean(float(x)^2, -1) + eps)), differentiable in x and weight."""
+    return _RMSNorm.apply(x, weight, float(eps))
+
+
+# --------------------------------------------------------------------------- rotary position embedding
+
+
+def _strides6(x: Tensor, out: Tensor):
+    return (C.c_int64 * 6)(x.stride(0), x.stride(1), x.stride(2), out.stride(0), out.stride(1), out.stride(2))
+
+
+def _launch_rope(q: Tensor, k: Tensor, cos: Tensor, sin: Tensor, inverse: bool) -> tuple[Tensor, Tensor]:
+    dev = q.device
+    lib = C.load()
+    b, hq, t, d = q.shape
+    qo, ko = torch.empty_like(q), torch.empty_like(k)  # same strides as the inputs
+    with torch.cuda.device(dev), C.timed("prl_rope", dev):
+        C.check(
+            lib.prl_rope(C.ptr(q), C.ptr(qo), _strides6(q, qo), hq, C.ptr(k), C.ptr(ko), _strides6(k, ko), k.shape[1],
+                         C.ptr(cos), C.ptr(sin), cos.stride(0), cos.stride(1), C.dtype_code(q), b, t, d, int(inverse),
+                         C.stream_ptr(dev)),
+            "prl_rope",
+        )
+    return qo, ko
+
+
+def _rope_ready(x: Tensor) -> Tensor:
+    """Last dimension contiguous, every other stride and the base address 16-byte aligned; else one copy."""
+    es = x.element_size()
+    if x.stride(-1) != 1 or x.data_ptr() % 16 or any((s * es) % 16 for s in x.stride()[:-1]):
+        return x.contiguous()
+    return x
+
+
+class _Rope(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q: Tensor, k: Tensor, cos: Tensor, sin: Tensor):
+        q, k = _rope_ready(q), _rope_ready(k)
+        ctx.save_for_backward(cos, sin)
+        return _launch_rope(q, k, cos, sin, False)
+
+    @staticmethod
+    def backward(ctx, gq: Tensor, gk: Tensor):
+        cos, sin = ctx.saved_tensors
+        gq, gk = _launch_rope(_rope_ready(gq), _rope_ready(gk), cos, sin, True)
+        return gq, gk, None, None
+
+
+def rope_supported(q: Tensor, k: Tensor, cos: Tensor, sin: Tensor) -> bool:
+    if q.ndim != 4 or k.ndim != 4 or cos.ndim != 3 or cos.shape != sin.shape or not q.is_cuda:
+        return False
+    if not (q.dtype == k.dtype == cos.dtype == sin.dtype) or q.dtype not in (torch.bfloat16, torch.float32):
+        return False
+    b, _, t, d = q.shape
+    if k.shape[0] != b or k.shape[2] != t or k.shape[3] != d or cos.shape != (b, t, d) or q.numel() == 0:
+        return False
+    es = q.element_size()
+    for c in (cos, sin):
+        if c.stride(-1) != 1 or c.data_ptr() % 16 or (c.stride(0) * es) % 16 or (c.stride(1) * es) % 16:
+            return False
+    if cos.stride() != sin.stride() or cos.requires_grad or sin.requires_grad:
+        return False
+    return bool(C.load().prl_rope_supported(C.dtype_code(q), d))
+
+
+def apply_rotary_pos_emb(q: Tensor, k: Tensor, cos: Tensor, sin: Tensor, unsqueeze_dim: int = 1):
+    """transformers' function of the same name ([batch, heads, seq, head_dim] layout, `unsqueeze_dim = 1`) on one
+    HIP launch for query and key together; other layouts go to the original."""
+    if unsqueeze_dim == 1 and rope_supported(q, k, cos, sin):
+        return _Rope.apply(q, k, cos, sin)
+    return _ORIGINAL_ROPE[0](q, k, cos, sin, unsqueeze_dim)
+
+
+_ORIGINAL_ROPE: list[Any] = []
+_PATCHED_MODULES: dict[str, Any] = {}
+
+
+def _fused_rmsnorm_forward(self: nn.Module, hidden_states: Tensor) -> Tensor:
+    weight = self.weight
+    if hasattr(weight, "to_local"):  # a DTensor outside an FSDP forward: leave it to torch
+        return self._prl_torch_forward(hidden_states)
+    if rms_norm_supported(hidden_states, weight):
+        return rms_norm(hidden_states, weight, self.variance_epsilon)
+    return self._prl_torch_forward(hidden_states)
+
+
+def fuse_model(model: nn.Module) -> dict[str, int]:
+    """Rebind the forward of every RMSNorm module of an HF causal LM to the HIP kernel.  Returns what was
+    rebound, by kind.  Call it before FSDP wrapping or after; parameters are left as they are."""
+    done = {"rmsnorm": 0, "rope": 0}
+    import sys
+
+    home = sys.modules.get(type(model).__module__)  # e.g. transformers.models.qwen3.modeling_qwen3
+    if home is not None and hasattr(home, "apply_rotary_pos_emb"):
+        if home.__name__ not in _PATCHED_MODULES:
+            _PATCHED_MODULES[home.__name__] = home.apply_rotary_pos_emb
+            if not _ORIGINAL_ROPE:
+                _ORIGINAL_ROPE.append(home.apply_rotary_pos_emb)
+            home.apply_rotary_pos_emb = apply_rotary_pos_emb  # module-wide: every model of this family in the process
+        done["rope"] = 1
+    for module in model.modules():
+        name = type(module).__name__
+        is_norm = name.endswith("RMSNorm") and hasattr(module, "weight") and hasattr(module, "variance_epsilon")
+        if is_norm and not hasattr(module, "_prl_torch_forward"):
+            module._prl_torch_forward = module.forward
+            module.forward = types.MethodType(_fused_rmsnorm_forward, module)
+            done["rmsnorm"] += 1
+    return done
+
+
+def unfuse_model(model: nn.Module) -> None:
+    import sys
+
+    home = sys.modules.get(type(model).__module__)
+    if home is not None and home.__name__ in _PATCHED_MODULES:
+        home.apply_rotary_pos_emb = _PATCHED_MODULES.pop(home.__name__)
+    for module in model.modules():
+        if hasattr(module, "_prl_torch_forward"):
+            module.forward = module._prl_torch_forward
+            del module._prl_torch_forward
+
+
+def describe(model: nn.Module) -> Any:
+    return sum(1 for m in model.modules() if hasattr(m, "_prl_torch_forward"))

@@ -51,6 +51,10 @@ def build_model(config: RLTrainerConfig, device: torch.device, mesh: Any, dtype:
         log(f"{mc.name}: no weights on this machine, training from a random initialisation")
     else:
         raise ValueError(f"model {mc.name!r} is neither a local directory nor one of {sorted(T.MODEL_DIMS)}")
+    if mc.impl == "liger_kernel":  # the reference's switch for fused block kernels; here they are HIP kernels
+        from .fused import fuse_model
+
+        log(f"fused block kernels: {fuse_model(model)}")
     if mc.ac is not None:
         from torch.distributed.algorithms._checkpoint.checkpoint_wrapper import checkpoint_wrapper
 

@@ -1,0 +1,167 @@
+"""Fused transformer-block kernels against the torch modules they stand in for."""
+
+import pytest
+import torch
+
+import prime_rl_cse_amd as prl  # noqa: F401
+from prime_rl_cse_amd import fused
+from tests.helpers import bf16_ulp_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def hf_rmsnorm(x, w, eps):
+    """The forward of transformers' Qwen2/Qwen3 RMSNorm module, verbatim arithmetic."""
+    dt = x.dtype
+    h = x.to(torch.float32)
+    var = h.pow(2).mean(-1, keepdim=True)
+    h = h * torch.rsqrt(var + eps)
+    return w * h.to(dt)
+
+
+@pytest.mark.parametrize("shape", [(1, 2048, 1024), (1, 2048, 16, 128), (1, 37, 896), (3, 5, 3584), (2, 4096), (1, 1, 8)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_rmsnorm_forward_and_backward(shape, dtype):
+    gen = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(shape, generator=gen) * 2).to(dtype).to(DEV)
+    w = (1 + 0.1 * torch.randn(shape[-1], generator=gen)).to(dtype).to(DEV)
+    gy = torch.randn(shape, generator=gen).to(dtype).to(DEV)
+    eps = 1e-6
+    assert fused.rms_norm_supported(x, w)
+
+    x1, w1 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y1 = fused.rms_norm(x1, w1, eps)
+    y1.backward(gy)
+    x0, w0 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y0 = hf_rmsnorm(x0, w0, eps)
+    y0.backward(gy)
+    # truth in float64 from the same (rounded) inputs
+    xd, wd, gd = x.double().requires_grad_(True), w.double().requires_grad_(True), gy.double()
+    yd = wd * (xd * torch.rsqrt(xd.pow(2).mean(-1, keepdim=True) + eps))
+    yd.backward(gd)
+
+    if dtype == torch.bfloat16:
+        assert bf16_ulp_close(y1.detach().cpu(), y0.detach().cpu(), ulps=1, atol=1e-6)
+        # input gradient: no further from the float64 value than torch's own bf16 chain, plus one rounding
+        err1 = (x1.grad.double() - xd.grad).abs()
+        err0 = (x0.grad.double() - xd.grad).abs()
+        tol = xd.grad.abs() * 2.0**-7 + 1e-6
+        assert bool((err1 <= torch.maximum(err0, tol)).all())
+        # weight gradient: as a vector, no further from the float64 value than torch's own bf16 chain (+ 50 %)
+        werr1 = (w1.grad.double() - wd.grad).norm().item()
+        werr0 = (w0.grad.double() - wd.grad).norm().item()
+        assert werr1 <= 1.5 * werr0 + 2.0**-8 * wd.grad.norm().item()
+    else:
+        assert torch.allclose(y1, y0, rtol=1e-6, atol=1e-6)
+        assert torch.allclose(x1.grad.double(), xd.grad, rtol=1e-4, atol=1e-5)
+        assert torch.allclose(w1.grad.double(), wd.grad, rtol=1e-4, atol=1e-3)
+    # same inputs, same bits
+    x2, w2 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    fused.rms_norm(x2, w2, eps).backward(gy)
+    assert torch.equal(x2.grad, x1.grad) and torch.equal(w2.grad, w1.grad)
+
+
+def test_rmsnorm_rows_with_a_stride_and_unsupported_shapes():
+    gen = torch.Generator().manual_seed(1)
+    wide = torch.randn(64, 1024 + 64, generator=gen).to(torch.bfloat16).to(DEV)
+    x = wide[:, :1024]  # rows further apart than H elements
+    w = torch.ones(1024, dtype=torch.bfloat16, device=DEV)
+    assert fused.rms_norm_supported(x, w)
+    assert bf16_ulp_close(fused.rms_norm(x, w, 1e-6).cpu(), hf_rmsnorm(x, w, 1e-6).cpu(), ulps=1, atol=1e-6)
+    assert not fused.rms_norm_supported(torch.randn(4, 1001, device=DEV).to(torch.bfloat16),
+                                        torch.ones(1001, dtype=torch.bfloat16, device=DEV))
+    assert not fused.rms_norm_supported(x, w.float())
+    assert not fused.rms_norm_supported(x.cpu(), w.cpu())
+
+
+def test_fuse_model_rebinds_every_norm_and_keeps_the_numbers():
+    from prime_rl_cse_amd import trainer as T
+
+    cfg = T.model_config("Qwen/Qwen3-0.6B", num_layers=2)
+    model = T.get_model(cfg, DEV, torch.bfloat16, seed=0)
+    ids = torch.randint(0, 1000, (1, 96), device=DEV)
+    pos = torch.arange(32, device=DEV).repeat(3)[None]
+    want = T.forward(model, ids, pos)
+    want.float().square().mean().backward()
+    grads = {n: p.grad.clone() for n, p in model.named_parameters()}
+    model.zero_grad(set_to_none=True)
+    done = fused.fuse_model(model)
+    assert done["rmsnorm"] == 2 * 4 + 1  # input, post-attention, query and key norms per block, final norm
+    got = T.forward(model, ids, pos)
+    got.float().square().mean().backward()
+    assert (got.float() - want.float()).abs().max().item() <= 0.05 * want.float().abs().max().item() + 1e-3
+    for n, p in model.named_parameters():
+        a, b = p.grad.float(), grads[n].float()
+        assert (a - b).norm().item() <= 0.05 * b.norm().item() + 1e-6, n
+    fused.unfuse_model(model)
+    assert fused.describe(model) == 0
+    assert torch.equal(T.forward(model, ids, pos), want)
+
+
+def hf_rope(q, k, cos, sin):
+    """transformers' apply_rotary_pos_emb with unsqueeze_dim = 1, verbatim arithmetic."""
+    def rotate_half(x):
+        return torch.cat((-x[..., x.shape[-1] // 2:], x[..., : x.shape[-1] // 2]), dim=-1)
+
+    cos, sin = cos.unsqueeze(1), sin.unsqueeze(1)
+    return (q * cos) + (rotate_half(q) * sin), (k * cos) + (rotate_half(k) * sin)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("b,t,hq,hk,d", [(1, 2048, 16, 8, 128), (2, 37, 14, 2, 64), (1, 5, 4, 4, 32)])
+def test_rope_forward_and_backward(dtype, b, t, hq, hk, d):
+    gen = torch.Generator().manual_seed(b * t + d)
+    # the layout the attention module produces: projections viewed as [b, t, heads, d], then transposed
+    q = torch.randn(b, t, hq, d, generator=gen).to(dtype).to(DEV).transpose(1, 2)
+    k = torch.randn(b, t, hk, d, generator=gen).to(dtype).to(DEV).transpose(1, 2)
+    ang = torch.rand(b, t, d // 2, generator=gen) * 6.28
+    ang = torch.cat((ang, ang), dim=-1)
+    cos, sin = ang.cos().to(dtype).to(DEV), ang.sin().to(dtype).to(DEV)
+    gq = torch.randn(b, hq, t, d, generator=gen).to(dtype).to(DEV)
+    gk = torch.randn(b, hk, t, d, generator=gen).to(dtype).to(DEV)
+    assert fused.rope_supported(q, k, cos, sin)
+
+    q1, k1 = q.detach().clone().requires_grad_(True), k.detach().clone().requires_grad_(True)
+    # keep the transposed layout for the leaf as well
+    q1 = q.detach().requires_grad_(True)
+    k1 = k.detach().requires_grad_(True)
+    qo1, ko1 = fused.apply_rotary_pos_emb(q1, k1, cos, sin)
+    torch.autograd.backward([qo1, ko1], [gq, gk])
+    qd, kd = q.double().requires_grad_(True), k.double().requires_grad_(True)
+    qod, kod = hf_rope(qd, kd, cos.double(), sin.double())
+    torch.autograd.backward([qod, kod], [gq.double(), gk.double()])
+    assert qo1.shape == q.shape and qo1.stride() == q.stride()
+    if dtype == torch.bfloat16:
+        for got, want in ((qo1, qod), (ko1, kod), (q1.grad, qd.grad), (k1.grad, kd.grad)):
+            assert bf16_ulp_close(got.detach().cpu(), want.detach().to(torch.bfloat16).cpu(), ulps=1, atol=1e-6)
+        # and no worse than the torch chain it replaces
+        q0, k0 = q.detach().requires_grad_(True), k.detach().requires_grad_(True)
+        qo0, ko0 = hf_rope(q0, k0, cos, sin)
+        assert (qo1.double() - qod).abs().max().item() <= (qo0.double() - qod).abs().max().item() + 1e-6
+    else:
+        for got, want in ((qo1, qod), (ko1, kod), (q1.grad, qd.grad), (k1.grad, kd.grad)):
+            assert torch.allclose(got.double(), want, rtol=1e-5, atol=1e-6)
+
+
+def test_fuse_model_patches_rope_and_whole_model_agrees():
+    from prime_rl_cse_amd import trainer as T
+
+    cfg = T.model_config("Qwen/Qwen3-0.6B", num_layers=2)
+    model = T.get_model(cfg, DEV, torch.bfloat16, seed=1)
+    ids = torch.randint(0, 1000, (1, 64), device=DEV)
+    pos = torch.arange(32, device=DEV).repeat(2)[None]
+    want = T.forward(model, ids, pos).float()
+    done = fused.fuse_model(model)
+    assert done["rope"] == 1
+    timer = prl._capi.KernelTimer()
+    prl._capi.set_timer(timer)
+    try:
+        got = T.forward(model, ids, pos).float()
+    finally:
+        prl._capi.set_timer(None)
+    torch.cuda.synchronize()
+    assert timer.summary()["prl_rope"]["launches"] == 2 and timer.summary()["prl_rmsnorm_fwd"]["launches"] == 9
+    assert (got - want).abs().max().item() <= 0.05 * want.abs().max().item() + 1e-3
+    fused.unfuse_model(model)
+    assert torch.equal(T.forward(model, ids, pos).float(), want)

@@ -14,6 +14,9 @@ layers = int(sys.argv[1]) if len(sys.argv) > 1 else 28
 blocks_per_group = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 cfg = T.model_config("Qwen/Qwen3-0.6B", num_layers=layers)
 model = T.get_model(cfg, dev, torch.float32, seed=0)
+if len(sys.argv) > 3 and sys.argv[3] == "fused":
+    from prime_rl_cse_amd import fused
+    print("fused:", fused.fuse_model(model))
 try:
     T.setup_fsdp(model, mesh, blocks_per_group=blocks_per_group)
 except TypeError:
@@ -33,6 +36,6 @@ pr = cProfile.Profile(); pr.enable()
 T.train_step(model, opt, batch, prl.LossConfig(), device=dev, samples=128)
 torch.cuda.synchronize()
 pr.disable()
-pstats.Stats(pr).sort_stats("tottime").print_stats(28)
+pstats.Stats(pr).sort_stats("tottime").print_stats(int(os.environ.get("PROFILE_LINES", "28")))
 import torch.distributed as dist
 dist.destroy_process_group()
