@@ -61,7 +61,9 @@ def build_model(config: RLTrainerConfig, device: torch.device, mesh: Any, dtype:
         for i, (name, block) in enumerate(list(model.model.layers.named_children())):
             if i % mc.ac.freq == 0:
                 model.model.layers.register_module(name, checkpoint_wrapper(block, preserve_rng_state=False))
-    T.setup_fsdp(model, mesh, DTYPES[mc.reduce_dtype], mc.reshard_after_forward)
+    # `reshard_after_forward = true` is the reference's default and means "not asked for": models that fit stay
+    # gathered for a whole step (trainer.keeps_parameters_gathered); `false` is honoured as given
+    T.setup_fsdp(model, mesh, DTYPES[mc.reduce_dtype], None if mc.reshard_after_forward else False)
     return model, cfg
 
 

@@ -87,8 +87,20 @@ def blocks_per_fsdp_group(model: nn.Module, target_bytes: int = 1 << 30) -> int:
     return max(1, min(len(blocks), target_bytes // max(per_block, 1)))
 
 
+KEEP_GATHERED_BYTES = 32 << 30  # bf16 parameters up to this size stay gathered for a whole optimizer step
+
+
+def keeps_parameters_gathered(model: nn.Module) -> bool:
+    """Whether the whole bf16 model is small enough (32 GB of the 288 GB) to stay gathered from the first
+    micro-batch of a step to the last.  Then a step costs ONE all-gather and ONE reduce-scatter per FSDP group
+    instead of two and one per micro-batch (the reference reshards after every forward and reduces after every
+    backward, src/prime_rl/trainer/model.py:110-134, src/prime_rl/trainer/rl/train.py:271-310): with the
+    gradients accumulated unsharded in fp32 the sums are the same, and xGMI carries 1/8 .. 1/16 of the bytes."""
+    return sum(p.numel() for p in model.parameters()) * 2 <= KEEP_GATHERED_BYTES
+
+
 def setup_fsdp(model: nn.Module, mesh: Any, reduce_dtype: torch.dtype = torch.float32,
-               reshard_after_forward: bool = True, blocks_per_group: int | None = None) -> nn.Module:
+               reshard_after_forward: bool | None = None, blocks_per_group: int | None = None) -> nn.Module:
     """FSDP2 over a 1-D data-parallel mesh as the reference sets it up
     (src/prime_rl/trainer/model.py:102-135): bf16 parameters on the wire, fp32
     gradient reduction, transformer blocks in groups (`blocks_per_group`, default
@@ -96,6 +108,9 @@ def setup_fsdp(model: nn.Module, mesh: Any, reduce_dtype: torch.dtype = torch.fl
     for untied models the embedding and [lm_head, final norm] get groups of their own."""
     from torch.distributed.fsdp import MixedPrecisionPolicy, fully_shard
 
+    if reshard_after_forward is None:  # not asked for either way: keep small models gathered
+        reshard_after_forward = not keeps_parameters_gathered(model)
+    model._prl_keep_gathered = not reshard_after_forward
     mp = MixedPrecisionPolicy(param_dtype=torch.bfloat16, reduce_dtype=reduce_dtype)
     blocks = list(model.model.layers)
     per = blocks_per_group if blocks_per_group else blocks_per_fsdp_group(model)
@@ -149,8 +164,14 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, micro_batches
     tensors = Tensors()
     tokens = 0
     for step_idx, host_mb in enumerate(micro_batches):
+        last = step_idx == len(micro_batches) - 1
         if hasattr(model, "set_requires_all_reduce"):
-            model.set_requires_all_reduce(step_idx == len(micro_batches) - 1)
+            model.set_requires_all_reduce(last)
+        if getattr(model, "_prl_keep_gathered", False) and hasattr(model, "set_requires_gradient_sync"):
+            # gradients accumulate unsharded (in the fp32 reduce dtype) and are reduce-scattered once, after the
+            # last micro-batch; the parameters stay gathered until then
+            model.set_requires_gradient_sync(last)
+            model.set_reshard_after_backward(last)
         mb = to_device(host_mb, device)
         logits = forward(model, mb["input_ids"], mb["position_ids"])
         loss, aux = policy_loss(logits, mb["input_ids"], mb["position_ids"], mb["advantages"], mb["logprobs"],
