@@ -125,9 +125,28 @@ def setup_fsdp(model: nn.Module, mesh: Any, reduce_dtype: torch.dtype = torch.fl
     return model
 
 
-def forward(model: nn.Module, input_ids: Tensor, position_ids: Tensor) -> Tensor:
-    """Logits [batch, seq, vocab] of a packed row (src/prime_rl/trainer/model.py:251-254)."""
-    return model(input_ids=input_ids, position_ids=position_ids).logits
+def forward(model: nn.Module, input_ids: Tensor, position_ids: Tensor, plan: Any = None) -> Tensor:
+    """Logits [batch, seq, vocab] of a packed row (src/prime_rl/trainer/model.py:251-254).  With a
+    `attention.PackedPlan` of that row, attention runs over the samples side by side instead of over the
+    whole row under a [T, T] mask; the logits are the same."""
+    if plan is None:
+        return model(input_ids=input_ids, position_ids=position_ids).logits
+    from . import attention
+
+    attention.install()
+    with attention.use_plan(plan):
+        return model(input_ids=input_ids, position_ids=position_ids).logits
+
+
+def attention_plan(host_micro_batch: MicroBatch, device: torch.device | str) -> Any:
+    """The side-by-side attention layout of one micro-batch, from its position ids while they are still on the
+    host (no device synchronisation); None when there is nothing to gain."""
+    from . import attention
+
+    pos = host_micro_batch["position_ids"]
+    if pos.is_cuda:
+        return None
+    return attention.plan_from_position_ids(pos, device)
 
 
 @dataclass
@@ -173,7 +192,7 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, micro_batches
             model.set_requires_gradient_sync(last)
             model.set_reshard_after_backward(last)
         mb = to_device(host_mb, device)
-        logits = forward(model, mb["input_ids"], mb["position_ids"])
+        logits = forward(model, mb["input_ids"], mb["position_ids"], attention_plan(host_mb, device))
         loss, aux = policy_loss(logits, mb["input_ids"], mb["position_ids"], mb["advantages"], mb["logprobs"],
                                 mb["loss_mask"], mb["temperature"], loss_config, loss_scale, skip_masked=True)
         del logits
@@ -220,7 +239,7 @@ def recompute_logprobs(logprob_model: nn.Module, micro_batches: list[MicroBatch]
     errors = []
     for mb in micro_batches:
         ids = mb["input_ids"].to(device)
-        logits = forward(logprob_model, ids, mb["position_ids"].to(device))
+        logits = forward(logprob_model, ids, mb["position_ids"].to(device), attention_plan(mb, device))
         lp = selective_log_softmax(shift_logits(logits) / mb["temperature"], ids)
         errors.append(torch.exp(lp - mb["logprobs"].to(device)))
         mb["logprobs"] = lp.cpu()

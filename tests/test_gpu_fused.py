@@ -165,3 +165,45 @@ def test_fuse_model_patches_rope_and_whole_model_agrees():
     assert (got - want).abs().max().item() <= 0.05 * want.abs().max().item() + 1e-3
     fused.unfuse_model(model)
     assert torch.equal(T.forward(model, ids, pos).float(), want)
+
+
+@pytest.mark.parametrize("lengths", [[32] * 6, [50, 7, 31, 64, 2, 40, 60, 33, 48, 21], [200]])
+def test_side_by_side_attention_gives_the_masked_row_attention(lengths):
+    from prime_rl_cse_amd import attention
+    from prime_rl_cse_amd import trainer as T
+
+    cfg = T.model_config("Qwen/Qwen3-0.6B", num_layers=2)
+    model = T.get_model(cfg, DEV, torch.bfloat16, seed=2)
+    t = sum(lengths)
+    gen = torch.Generator().manual_seed(t)
+    ids = torch.randint(0, 1000, (1, t), generator=gen)
+    pos = torch.cat([torch.arange(n) for n in lengths])[None]
+    plan = attention.plan_from_position_ids(pos, DEV)
+    if len(lengths) == 1:
+        assert plan is None  # one sample: nothing to lay side by side
+        return
+    assert plan.n == len(lengths) and plan.lmax == max(lengths) and plan.equal == (len(set(lengths)) == 1)
+    want = T.forward(model, ids.to(DEV), pos.to(DEV))
+    want.float().square().mean().backward()
+    grads = {n: p.grad.clone() for n, p in model.named_parameters()}
+    model.zero_grad(set_to_none=True)
+    got = T.forward(model, ids.to(DEV), pos.to(DEV), plan)
+    got.float().square().mean().backward()
+    scale = want.float().abs().max().item()
+    assert (got.float() - want.float()).abs().max().item() <= 0.03 * scale
+    for n, p in model.named_parameters():
+        a, b = p.grad.float(), grads[n].float()
+        assert (a - b).norm().item() <= 0.03 * b.norm().item() + 1e-6, n
+    # a different row afterwards, without a plan, still takes the masked path
+    again = T.forward(model, ids.to(DEV), pos.to(DEV))
+    assert torch.equal(again, want)
+
+
+def test_plan_declines_when_padding_would_not_pay():
+    from prime_rl_cse_amd import attention
+
+    pos = torch.cat([torch.arange(900), torch.arange(50), torch.arange(50)])[None]
+    assert attention.plan_from_position_ids(pos, "cpu") is None  # one sample dominates: 3 * 900^2 > T^2 / 2
+    pos = torch.cat([torch.arange(128)] * 16)[None]
+    plan = attention.plan_from_position_ids(pos, "cpu")
+    assert plan.equal and plan.n == 16 and plan.gather is None
