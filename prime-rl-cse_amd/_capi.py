@@ -149,6 +149,30 @@ def require_device(*tensors: torch.Tensor) -> torch.device:
     return dev
 
 
+class _OnDevice:
+    """`with on_device(dev):` makes `dev` current for the launches inside; when it already is (the usual case:
+    one process per GPU) entering and leaving cost nothing."""
+
+    __slots__ = ("ctx",)
+
+    def __init__(self, device: torch.device):
+        self.ctx = None if device.index is None or torch.cuda.current_device() == device.index else \
+            torch.cuda.device(device)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            return self.ctx.__exit__(*exc)
+        return False
+
+
+def on_device(device: torch.device) -> _OnDevice:
+    return _OnDevice(device)
+
+
 def stream_ptr(device: torch.device) -> c_void_p:
     return c_void_p(torch.cuda.current_stream(device).cuda_stream)
 

@@ -22,7 +22,7 @@ def group_advantage(rewards: Tensor, completion_lengths: Tensor | None, samples_
     r = rewards.reshape(-1).to(torch.float32).contiguous()
     n = None if completion_lengths is None else completion_lengths.reshape(-1).to(torch.int64).contiguous()
     out = torch.empty_like(r)
-    with torch.cuda.device(dev):
+    with C.on_device(dev):
         C.check(
             lib.prl_group_advantage(
                 C.ptr(r), C.ptr(n), r.numel(), samples_per_problem, C.ADVANTAGE_KIND[advantage_type], C.ptr(out),

@@ -36,7 +36,7 @@ class _RMSNorm(torch.autograd.Function):
         w = weight.contiguous()
         y = torch.empty((rows, h), dtype=x.dtype, device=dev)
         rstd = torch.empty(rows, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev), C.timed("prl_rmsnorm_fwd", dev):
+        with C.on_device(dev), C.timed("prl_rmsnorm_fwd", dev):
             C.check(
                 lib.prl_rmsnorm_fwd(C.ptr(x2), x2.stride(0) if rows > 1 else h, C.ptr(w), C.ptr(y), h, C.ptr(rstd),
                                     C.dtype_code(x), rows, h, eps, C.stream_ptr(dev)),
@@ -60,7 +60,7 @@ class _RMSNorm(torch.autograd.Function):
         code = C.dtype_code(x2)
         ws_bytes = lib.prl_rmsnorm_bwd_workspace_bytes(code, rows, h)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev), C.timed("prl_rmsnorm_bwd", dev):
+        with C.on_device(dev), C.timed("prl_rmsnorm_bwd", dev):
             C.check(
                 lib.prl_rmsnorm_bwd(C.ptr(x2), x2.stride(0) if rows > 1 else h, C.ptr(w), C.ptr(rstd), C.ptr(g2),
                                     g2.stride(0) if rows > 1 else h, C.ptr(gx), h, C.ptr(gw), code, rows, h,
@@ -68,6 +68,9 @@ class _RMSNorm(torch.autograd.Function):
                 "prl_rmsnorm_bwd",
             )
         return gx.view(ctx.shape), gw, None
+
+
+_NORM_SHAPES: dict[tuple[torch.dtype, int], bool] = {}
 
 
 def rms_norm_supported(x: Tensor, weight: Tensor) -> bool:
@@ -82,7 +85,11 @@ def rms_norm_supported(x: Tensor, weight: Tensor) -> bool:
         return False
     if x.ndim >= 2 and x.shape[:-1].numel() > 1 and any((s * es) % 16 for s in x.stride()[:-1]):
         return False
-    return bool(C.load().prl_rmsnorm_supported(C.dtype_code(x), h))
+    key = (x.dtype, h)
+    ok = _NORM_SHAPES.get(key)
+    if ok is None:
+        ok = _NORM_SHAPES[key] = bool(C.load().prl_rmsnorm_supported(C.dtype_code(x), h))
+    return ok
 
 
 def rms_norm(x: Tensor, weight: Tensor, eps: float) -> Tensor:
@@ -102,7 +109,7 @@ def _launch_rope(q: Tensor, k: Tensor, cos: Tensor, sin: Tensor, inverse: bool) 
     lib = C.load()
     b, hq, t, d = q.shape
     qo, ko = torch.empty_like(q), torch.empty_like(k)  # same strides as the inputs
-    with torch.cuda.device(dev), C.timed("prl_rope", dev):
+    with C.on_device(dev), C.timed("prl_rope", dev):
         C.check(
             lib.prl_rope(C.ptr(q), C.ptr(qo), _strides6(q, qo), hq, C.ptr(k), C.ptr(ko), _strides6(k, ko), k.shape[1],
                          C.ptr(cos), C.ptr(sin), cos.stride(0), cos.stride(1), C.dtype_code(q), b, t, d, int(inverse),

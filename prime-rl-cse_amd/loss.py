@@ -94,7 +94,7 @@ def _launch_fwd(
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
     code = C.dtype_code(logits)
     st = C.stream_ptr(dev)
-    with torch.cuda.device(dev), C.timed("prl_logprob_entropy_fwd", dev):
+    with C.on_device(dev), C.timed("prl_logprob_entropy_fwd", dev):
         for i in range(b):
             C.check(
                 lib.prl_logprob_entropy_fwd(
@@ -118,7 +118,7 @@ def _launch_bwd(
     g = g.to(torch.float32).contiguous()
     code = C.dtype_code(logits)
     st = C.stream_ptr(dev)
-    with torch.cuda.device(dev), C.timed("prl_logprob_bwd", dev):
+    with C.on_device(dev), C.timed("prl_logprob_bwd", dev):
         for i in range(b):
             C.check(
                 lib.prl_logprob_bwd(
@@ -208,7 +208,7 @@ def _launch_loss(
     g = torch.empty(t, dtype=torch.float32, device=dev)
     seg_loss = torch.empty(max(max_seg, 1), dtype=torch.float32, device=dev)
     mask_u8 = mask.contiguous().view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8).contiguous()
-    with torch.cuda.device(dev), C.timed("prl_grpo_loss", dev):
+    with C.on_device(dev), C.timed("prl_grpo_loss", dev):
         C.check(
             lib.prl_grpo_loss(
                 C.ptr(lp), C.ptr(old), C.ptr(adv), C.ptr(mask_u8), C.ptr(seg_start), C.ptr(n_seg), max_seg, t,
@@ -293,7 +293,7 @@ def segments_from_position_ids(position_ids: Tensor) -> tuple[Tensor, Tensor, Te
     seg_id = torch.empty(t, dtype=torch.int32, device=dev)
     seg_start = torch.empty(t + 1, dtype=torch.int64, device=dev)
     n_seg = torch.empty(1, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev), C.timed("prl_segments_from_position_ids", dev):
+    with C.on_device(dev), C.timed("prl_segments_from_position_ids", dev):
         C.check(
             lib.prl_segments_from_position_ids(
                 C.ptr(pos), t, C.ptr(seg_id), C.ptr(seg_start), C.ptr(n_seg), C.stream_ptr(dev)
@@ -373,7 +373,7 @@ class _PolicyLoss(torch.autograd.Function):
         )
         if single_pass:
             dlogits = torch.empty((1, t, v), dtype=logits.dtype, device=dev)
-            with torch.cuda.device(dev):
+            with C.on_device(dev):
                 with C.timed("prl_policy_rows_fwd_bwd", dev):
                     C.check(
                         lib.prl_policy_rows_fwd_bwd(
@@ -396,7 +396,7 @@ class _PolicyLoss(torch.autograd.Function):
         else:
             ws_bytes = lib.prl_logprob_workspace_bytes(t, v)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
-            with torch.cuda.device(dev), C.timed("prl_policy_forward", dev):
+            with C.on_device(dev), C.timed("prl_policy_forward", dev):
                 C.check(
                     lib.prl_policy_forward(
                         C.ptr(logits), code, t, v, logits.stride(1), C.ptr(ids), C.ptr(pos), C.ptr(adv),
@@ -433,7 +433,7 @@ class _PolicyLoss(torch.autograd.Function):
             if unit is not None and grad_loss.data_ptr() == unit.data_ptr():
                 return (d,) + (None,) * 9  # the caller passed unit_gradient(): known to be 1
             _, t, v = d.shape
-            with torch.cuda.device(dev), C.timed("prl_scale_rows_if_not_one", dev):
+            with C.on_device(dev), C.timed("prl_scale_rows_if_not_one", dev):
                 C.check(
                     C.load().prl_scale_rows_if_not_one(C.ptr(d), C.dtype_code(d), t, v, v, C.ptr(gscale),
                                                        C.stream_ptr(dev)),

@@ -45,7 +45,7 @@ def masked_stats(x: Tensor, mask: Tensor | None = None) -> tuple[Tensor, Tensor]
     count = torch.empty(1, dtype=torch.int64, device=dev)
     ws_bytes = lib.prl_masked_stats_workspace_bytes()
     ws = torch.empty((ws_bytes + 7) // 8, dtype=torch.int64, device=dev)
-    with torch.cuda.device(dev):
+    with C.on_device(dev):
         C.check(
             lib.prl_masked_stats(
                 C.ptr(xf), C.ptr(m8), xf.numel(), C.ptr(out), C.ptr(count), C.ptr(ws), ws.numel() * 8,
@@ -150,7 +150,7 @@ class Tensors(defaultdict):
         out = torch.empty((n_keys, 5), dtype=torch.float32, device=dev)
         multi = dist.is_initialized() and dist.get_world_size() > 1
         st = C.stream_ptr(dev)
-        with torch.cuda.device(dev), C.timed("prl_stats", dev):
+        with C.on_device(dev), C.timed("prl_stats", dev):
             C.check(lib.prl_stats_begin(C.ptr(ws), n_keys, st), "prl_stats_begin")
             for level in range(4):
                 C.check(lib.prl_stats_pass(level, table, n_pieces, n_keys, C.ptr(ws), st), "prl_stats_pass")
