@@ -251,6 +251,18 @@ int prl_rope(const void* q, void* q_out, const int64_t* q_strides, int64_t q_hea
              int64_t cs_token_stride, int dtype, int64_t B, int64_t T, int64_t D, int inverse, void* stream);
 
 /*
+ * out = silu(gate) * up over n contiguous elements, and the backward
+ *   gup = gout * silu(gate),  ggate = gout * up * silu'(gate).
+ * The gated MLP activation of the transformer blocks; third kernel of the
+ * reference's `model.impl = "liger_kernel"` switch
+ * (src/prime_rl/trainer/model.py:74-75).  All tensors share `dtype` (bf16 or
+ * fp32), are 16-byte aligned, and n is a multiple of 8 (bf16) or 4 (fp32).
+ */
+int prl_swiglu_fwd(const void* gate, const void* up, void* out, int dtype, int64_t n, void* stream);
+int prl_swiglu_bwd(const void* gate, const void* up, const void* gout, void* ggate, void* gup, int dtype, int64_t n,
+                   void* stream);
+
+/*
  * Group-relative advantages: B rewards in consecutive groups of G.  Replaces
  * compute_advantages (src/prime_rl/orchestrator/advantage.py:71-103) for the
  * four kinds of its REGISTRY (:63-68).  `lengths` (int64 [B], completion

@@ -68,6 +68,8 @@ SIGNATURES = {
          c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p],
     ),
     "prl_scale_rows_if_not_one": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
+    "prl_swiglu_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
+    "prl_swiglu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     "prl_rope_supported": (c_int, [c_int, c_int64]),
     "prl_rope": (
         c_int,

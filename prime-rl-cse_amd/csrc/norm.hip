@@ -395,3 +395,100 @@ extern "C" int prl_rope(const void* q, void* q_out, const int64_t* q_strides, in
   PRL_CHECK_LAUNCH("rope");
   return PRL_OK;
 }
+
+// ---------------------------------------------------------------- SwiGLU
+//
+// out = silu(gate) * up, and its backward, element-wise over contiguous tensors (the gated MLP of the
+// transformer blocks: down_proj(act_fn(gate_proj(x)) * up_proj(x))); the third of the three kernels behind
+// the reference's `model.impl = "liger_kernel"` (src/prime_rl/trainer/model.py:74-75).  One launch forward
+// (torch: 2), one backward (torch: 5), and the activation's output is not kept for the backward.
+namespace prl {
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_swiglu_fwd(const char* __restrict__ gate, const char* __restrict__ up,
+                                                    char* __restrict__ out, int64_t nvec) {
+  constexpr int VE = DT == PRL_F32 ? 4 : 8;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
+    float g[VE], u[VE], o[VE];
+    load_vec<DT>(gate, v, g);
+    load_vec<DT>(up, v, u);
+#pragma unroll
+    for (int i = 0; i < VE; ++i) o[i] = round_to(g[i] * sigmoidf_(g[i]), DT) * u[i];  // torch rounds silu's output first
+    store_unit<DT, VE>(out, v, o);
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_swiglu_bwd(const char* __restrict__ gate, const char* __restrict__ up,
+                                                    const char* __restrict__ gout, char* __restrict__ ggate,
+                                                    char* __restrict__ gup, int64_t nvec) {
+  constexpr int VE = DT == PRL_F32 ? 4 : 8;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
+    float g[VE], u[VE], d[VE], dg[VE], du[VE];
+    load_vec<DT>(gate, v, g);
+    load_vec<DT>(up, v, u);
+    load_vec<DT>(gout, v, d);
+#pragma unroll
+    for (int i = 0; i < VE; ++i) {
+      const float s = sigmoidf_(g[i]);
+      du[i] = d[i] * round_to(g[i] * s, DT);
+      dg[i] = round_to(d[i] * u[i], DT) * (s * (1.0f + g[i] * (1.0f - s)));
+    }
+    store_unit<DT, VE>(ggate, v, dg);
+    store_unit<DT, VE>(gup, v, du);
+  }
+}
+
+}  // namespace prl
+
+static int swiglu_check(const char* who, int dtype, int64_t n, const void* a, const void* b, const void* c) {
+  if (dtype != PRL_F32 && dtype != PRL_BF16) {
+    prl::set_error("%s: unsupported dtype code %d", who, dtype);
+    return PRL_EDTYPE;
+  }
+  const int ve = dtype == PRL_F32 ? 4 : 8;
+  PRL_REQUIRE(n >= 0 && n % ve == 0, "%s: the element count must be a multiple of %d", who, ve);
+  PRL_REQUIRE(n == 0 || (a && b && c), "%s: tensors must not be NULL", who);
+  PRL_REQUIRE(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0,
+              "%s: tensors must be 16-byte aligned", who);
+  return PRL_OK;
+}
+
+extern "C" int prl_swiglu_fwd(const void* gate, const void* up, void* out, int dtype, int64_t n, void* stream) {
+  clear_error();
+  int rc = swiglu_check("swiglu_fwd", dtype, n, gate, up, out);
+  if (rc != PRL_OK || n == 0) return rc;
+  const int64_t nvec = n / (dtype == PRL_F32 ? 4 : 8);
+  const int64_t want = (nvec + 255) / 256;
+  const dim3 grid((unsigned)(want < 8192 ? want : 8192));
+  if (dtype == PRL_BF16)
+    hipLaunchKernelGGL((prl::k_swiglu_fwd<PRL_BF16>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)gate,
+                       (const char*)up, (char*)out, nvec);
+  else
+    hipLaunchKernelGGL((prl::k_swiglu_fwd<PRL_F32>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)gate,
+                       (const char*)up, (char*)out, nvec);
+  PRL_CHECK_LAUNCH("swiglu_fwd");
+  return PRL_OK;
+}
+
+extern "C" int prl_swiglu_bwd(const void* gate, const void* up, const void* gout, void* ggate, void* gup, int dtype,
+                              int64_t n, void* stream) {
+  clear_error();
+  int rc = swiglu_check("swiglu_bwd", dtype, n, gate, up, gout);
+  if (rc != PRL_OK) return rc;
+  rc = swiglu_check("swiglu_bwd", dtype, n, ggate, gup, gout);
+  if (rc != PRL_OK || n == 0) return rc;
+  const int64_t nvec = n / (dtype == PRL_F32 ? 4 : 8);
+  const int64_t want = (nvec + 255) / 256;
+  const dim3 grid((unsigned)(want < 8192 ? want : 8192));
+  if (dtype == PRL_BF16)
+    hipLaunchKernelGGL((prl::k_swiglu_bwd<PRL_BF16>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)gate,
+                       (const char*)up, (const char*)gout, (char*)ggate, (char*)gup, nvec);
+  else
+    hipLaunchKernelGGL((prl::k_swiglu_bwd<PRL_F32>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)gate,
+                       (const char*)up, (const char*)gout, (char*)ggate, (char*)gup, nvec);
+  PRL_CHECK_LAUNCH("swiglu_bwd");
+  return PRL_OK;
+}

@@ -7,7 +7,8 @@ kernels for RMSNorm, RoPE and SwiGLU into the HF model
 model's normalisation modules to `rms_norm` (one HIP launch forward and two
 backward instead of ~22 small torch kernels) and the model family's
 `apply_rotary_pos_emb` to one launch for query and key together (instead of
-~14 forward and ~20 backward).  Modules whose shape or dtype the
+~14 forward and ~20 backward), and the gated MLPs' `silu(gate) * up` to one
+launch each way (instead of 2 and 5).  Modules whose shape or dtype the
 kernels do not cover keep their torch forward (on the same device; nothing
 moves to the host).
 """
@@ -166,6 +167,53 @@ def apply_rotary_pos_emb(q: Tensor, k: Tensor, cos: Tensor, sin: Tensor, unsquee
     return _ORIGINAL_ROPE[0](q, k, cos, sin, unsqueeze_dim)
 
 
+# --------------------------------------------------------------------------- SwiGLU
+
+
+class _SwiGLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gate: Tensor, up: Tensor):
+        dev = gate.device
+        out = torch.empty_like(gate)
+        with C.on_device(dev), C.timed("prl_swiglu_fwd", dev):
+            C.check(C.load().prl_swiglu_fwd(C.ptr(gate), C.ptr(up), C.ptr(out), C.dtype_code(gate), gate.numel(),
+                                            C.stream_ptr(dev)), "prl_swiglu_fwd")
+        ctx.save_for_backward(gate, up)  # the activation's output is recomputed in the backward, not kept
+        return out
+
+    @staticmethod
+    def backward(ctx, gout: Tensor):
+        gate, up = ctx.saved_tensors
+        dev = gate.device
+        if not gout.is_contiguous() or gout.data_ptr() % 16:
+            gout = gout.contiguous()
+        ggate, gup = torch.empty_like(gate), torch.empty_like(up)
+        with C.on_device(dev), C.timed("prl_swiglu_bwd", dev):
+            C.check(C.load().prl_swiglu_bwd(C.ptr(gate), C.ptr(up), C.ptr(gout), C.ptr(ggate), C.ptr(gup),
+                                            C.dtype_code(gate), gate.numel(), C.stream_ptr(dev)), "prl_swiglu_bwd")
+        return ggate, gup
+
+
+def swiglu_supported(gate: Tensor, up: Tensor) -> bool:
+    if not gate.is_cuda or gate.dtype != up.dtype or gate.dtype not in (torch.bfloat16, torch.float32):
+        return False
+    if gate.shape != up.shape or not gate.is_contiguous() or not up.is_contiguous() or gate.numel() == 0:
+        return False
+    return gate.numel() % (16 // gate.element_size()) == 0 and gate.data_ptr() % 16 == 0 and up.data_ptr() % 16 == 0
+
+
+def swiglu(gate: Tensor, up: Tensor) -> Tensor:
+    """silu(gate) * up, differentiable in both."""
+    return _SwiGLU.apply(gate, up)
+
+
+def _fused_mlp_forward(self: nn.Module, x: Tensor) -> Tensor:
+    gate, up = self.gate_proj(x), self.up_proj(x)
+    if swiglu_supported(gate, up):
+        return self.down_proj(swiglu(gate, up))
+    return self.down_proj(self.act_fn(gate) * up)
+
+
 _ORIGINAL_ROPE: list[Any] = []
 _PATCHED_MODULES: dict[str, Any] = {}
 
@@ -182,7 +230,7 @@ def _fused_rmsnorm_forward(self: nn.Module, hidden_states: Tensor) -> Tensor:
 def fuse_model(model: nn.Module) -> dict[str, int]:
     """Rebind the forward of every RMSNorm module of an HF causal LM to the HIP kernel.  Returns what was
     rebound, by kind.  Call it before FSDP wrapping or after; parameters are left as they are."""
-    done = {"rmsnorm": 0, "rope": 0}
+    done = {"rmsnorm": 0, "rope": 0, "swiglu": 0}
     import sys
 
     home = sys.modules.get(type(model).__module__)  # e.g. transformers.models.qwen3.modeling_qwen3
@@ -200,6 +248,12 @@ def fuse_model(model: nn.Module) -> dict[str, int]:
             module._prl_torch_forward = module.forward
             module.forward = types.MethodType(_fused_rmsnorm_forward, module)
             done["rmsnorm"] += 1
+        is_gated_mlp = name.endswith("MLP") and all(hasattr(module, a) for a in ("gate_proj", "up_proj", "down_proj")) \
+            and type(getattr(module, "act_fn", None)).__name__ in ("SiLU", "SiLUActivation")
+        if is_gated_mlp and not hasattr(module, "_prl_torch_forward"):
+            module._prl_torch_forward = module.forward
+            module.forward = types.MethodType(_fused_mlp_forward, module)
+            done["swiglu"] += 1
     return done
 
 
