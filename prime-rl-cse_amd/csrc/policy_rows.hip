@@ -232,7 +232,9 @@ __global__ __launch_bounds__(kRowThreads) void k_policy_rows(
 #if PRL_ROWS_TRACE
   const uint64_t tick2 = wall_clock64();  // all chunks arrived and summed, in every wave
 #endif
-  if (!(s <= 3.0e38f) || !(s > 0.0f)) {  // overflow (or a NaN / -inf sample): exact two-pass soft-max
+  // overflow of either sum (x 2^(..) overflows before 2^(..) does), or a NaN / -inf sample: exact two-pass
+  // soft-max.  A NaN in w alone (0 * -inf from a masked-out vocabulary entry) is the reference's result too.
+  if (!(s <= 3.0e38f) || !(s > 0.0f) || fabsf(w) > 3.0e38f) {
     __syncthreads();                     // every wave has read the first round's sums before they are rewritten
     mx = kNegBig;
 #pragma unroll

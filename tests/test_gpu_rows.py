@@ -227,3 +227,51 @@ def test_incoming_gradient_other_than_one_and_second_backward():
     loss3, aux3 = prl.policy_loss(x3, *args)
     assert not loss3.requires_grad
     close(loss3, loss2, atol=1e-6)
+
+
+def test_rows_kernel_special_values_follow_the_two_kernel_path():
+    """Rows that make the sampled reference point useless (a huge logit far from every first chunk), rows with
+    -inf, +inf and NaN logits, and a label outside the vocabulary: same numbers and the same NaN pattern as the
+    two-kernel path, which follows the reference's arithmetic."""
+    import os
+
+    vocab, t = 32768, 12
+    gen = torch.Generator().manual_seed(77)
+    logits = (torch.randn(1, t, vocab, generator=gen) * 2).to(torch.bfloat16)
+    logits[0, 1] = -200.0
+    logits[0, 1, 20000] = 200.0      # exp2 of the difference overflows against any sampled reference: exact fallback
+    logits[0, 2, 30000] = 90.0       # large but summable
+    logits[0, 3, 100:200] = float("-inf")  # masked-out vocabulary entries: entropy becomes NaN (0 * -inf), as in torch
+    logits[0, 4, 5] = float("inf")
+    logits[0, 5, 7] = float("nan")
+    logits[0, 6] = -300.0            # a constant row far below zero
+    ids = torch.randint(0, vocab, (t,), generator=gen)
+    ids[2] = 20000                   # the label of the overflow row (token 2 is scored by row 1)
+    ids[8] = vocab + 3               # out of range
+    pos = torch.arange(t)
+    mask = torch.ones(t, dtype=torch.bool)
+    adv = torch.randn(t, generator=gen)
+    old = torch.full((t,), -10.0)
+    old[2] = 0.0
+    b = lambda x: x.unsqueeze(0).to(DEV)
+    out = {}
+    for flag in ("1", "0"):
+        os.environ["PRL_FUSED_ROWS"] = flag
+        try:
+            x = logits.to(DEV).requires_grad_(True)
+            loss, aux = prl.policy_loss(x, b(ids), b(pos), b(adv), b(old), b(mask), 1.0, prl.LossConfig(clip_ratio=1e9), t)
+            loss.backward()
+            out[flag] = (aux["logprobs"][0].cpu(), aux["entropy"][0].cpu(), x.grad[0].float().cpu())
+        finally:
+            os.environ.pop("PRL_FUSED_ROWS", None)
+    (lp1, en1, g1), (lp0, en0, g0) = out["1"], out["0"]
+    assert torch.equal(lp1.isnan(), lp0.isnan()) and torch.equal(en1.isnan(), en0.isnan())
+    assert lp1.isnan().tolist() == [False] * 5 + [True, True, False, True, False, False, False]  # +inf, NaN rows, bad label
+    assert en1.isnan()[4] and not en1.isnan()[2]
+    close(lp1, lp0, atol=2e-5)
+    close(en1, en0, atol=2e-5)
+    assert abs(lp1[2].item()) < 1e-5          # the 200 logit takes all the probability
+    assert abs(lp1[7].item() + math.log(vocab)) < 1e-4  # constant row: uniform
+    assert torch.equal(g1.isnan(), g0.isnan())
+    fin = ~g1.isnan()
+    assert bf16_ulp_close(g1[fin].to(torch.bfloat16), g0[fin].to(torch.bfloat16), ulps=1, atol=1e-9)
