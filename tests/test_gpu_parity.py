@@ -620,3 +620,25 @@ def test_long_row_takes_the_multi_kernel_bookkeeping_path(rtype):
     n = int(aux["n_seg"].item())
     starts = aux["seg_start"][: n + 1].cpu()
     assert (starts[1:] - starts[:-1]).tolist() == want["lengths"]
+
+
+def test_statistics_on_a_stream_of_their_own_give_the_same_numbers(monkeypatch):
+    gen = torch.Generator().manual_seed(9)
+    xs = [torch.randn(3000, generator=gen).to(DEV) for _ in range(4)]
+    ms = [(torch.rand(3000, generator=gen) < 0.5).to(DEV) for _ in range(4)]
+
+    def run():
+        t = prl.Tensors()
+        for x, m in zip(xs, ms):
+            t.add("a", x, m)
+            t.add("b", x, None, exp=True)
+        fut = t.compute_stats_async()
+        # work enqueued after the statistics must not disturb them
+        for x in xs:
+            x.add_(0.0)
+        return fut.result()
+
+    want = run()
+    monkeypatch.setenv("PRL_STATS_STREAM", "1")
+    got = run()
+    assert got == want
