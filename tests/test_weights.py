@@ -202,3 +202,42 @@ def test_weight_broadcast_between_trainer_and_inference_ranks_over_gloo():
         assert p.exitcode == 0
     assert out[0] == "sent" and out[1] == "skipped"
     assert out[2] == [(3, True), (4, True), (5, True)]
+
+
+@pytest.mark.gpu
+def test_weight_broadcast_as_a_publisher_subscriber_over_rccl(tmp_path, monkeypatch):
+    """The sender half on the GPU through RCCL: a one-member group is all this box has, so the broadcasts have
+    no receiver, but the bucket is packed on the publication stream from the gathered bf16 tensors and every
+    collective is issued for real.  The bucket must hold exactly what the published file holds."""
+    import torch.distributed as dist
+
+    from prime_rl_cse_amd.weights import WeightBroadcast
+
+    for k, v in dict(MASTER_ADDR="127.0.0.1", MASTER_PORT="29771", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0").items():
+        monkeypatch.setenv(k, v)
+    reset_world()
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", device_id=dev)
+    try:
+        torch.manual_seed(2)
+        model = nn.Sequential(nn.Linear(256, 512), nn.Linear(512, 64)).to(dev)
+        pub = WeightPublisher(tmp_path, async_level=1, device=dev)
+        ch = WeightBroadcast(None, src=0, device=dev)
+        pub.add_device_subscriber(ch.send)
+        for step in (1, 2):
+            with torch.no_grad():
+                for p in model.parameters():
+                    p.add_(0.5)
+            path = pub.publish(model, step=step).wait(timeout=60)
+            torch.cuda.synchronize()
+            state = torch.load(path, weights_only=True)
+            views = ch._views(ch._buckets[0])
+            assert set(views) == set(state)
+            for k, v in state.items():
+                assert torch.equal(views[k].cpu(), v), (step, k)
+            pub.guard_parameters()
+        ch.close()
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+        reset_world()
