@@ -15,7 +15,11 @@
 namespace prl {
 
 constexpr int kNormThreads = 256;
-constexpr int kNormMaxBlocks = 128;  // also the number of partial rows the weight-gradient finish adds up
+#ifndef PRL_NORM_MAX_BLOCKS
+#define PRL_NORM_MAX_BLOCKS 256  // backward: also the number of partial rows the weight-gradient finish adds up
+#endif
+constexpr int kNormMaxBlocks = PRL_NORM_MAX_BLOCKS;
+constexpr int kNormFwdMaxBlocks = 1024;  // forward: no partial sums, more workgroups only help (tools/tune_norm.py)
 
 template <int LPR>
 __device__ __forceinline__ float row_sum(float v) {
@@ -156,30 +160,31 @@ __global__ __launch_bounds__(kNormThreads) void k_rmsnorm_bwd(const char* __rest
 }
 
 // out[c] = sum over the partial rows of part[p, c], in a fixed order.  A workgroup owns 32 columns; its
-// 8 groups of 32 threads each take every 8th partial row (loads of 128 contiguous bytes), then the
+// 32 groups of 32 threads each take every 32nd partial row (loads of 128 contiguous bytes), then the
 // groups' sums are added through LDS.
 template <int DT>
-__global__ __launch_bounds__(256) void k_colsum_finish(const float* __restrict__ part, int nparts, int H,
-                                                       char* __restrict__ out) {
-  __shared__ float lds[8][32];
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
+__global__ __launch_bounds__(1024) void k_colsum_finish(const float* __restrict__ part, int nparts, int H,
+                                                        char* __restrict__ out) {
+  __shared__ float lds[32][33];
+  const int lc = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + lc;
   float s = 0.0f;
   if (c < H)
-    for (int p = g; p < nparts; p += 8) s += part[(int64_t)p * H + c];
-  lds[g][threadIdx.x & 31] = s;
+    for (int p = g; p < nparts; p += 32) s += part[(int64_t)p * H + c];
+  lds[g][lc] = s;
   __syncthreads();
   if (g == 0 && c < H) {
-    float t = lds[0][threadIdx.x];
+    float t = lds[0][lc];
 #pragma unroll
-    for (int k = 1; k < 8; ++k) t += lds[k][threadIdx.x];
+    for (int k = 1; k < 32; ++k) t += lds[k][lc];
     store_elem<DT>(out, c, t);
   }
 }
 
-static int norm_blocks(int64_t rows, int lpr) {
+static int norm_blocks(int64_t rows, int lpr, int cap = kNormMaxBlocks) {
   const int64_t rpb = kNormThreads / lpr;
   const int64_t want = (rows + rpb - 1) / rpb;
-  return (int)(want < kNormMaxBlocks ? (want > 0 ? want : 1) : kNormMaxBlocks);
+  return (int)(want < cap ? (want > 0 ? want : 1) : cap);
 }
 static int norm_lpr(int64_t H, int ve) { return H / ve <= 16 ? 16 : 64; }
 static int norm_nv(int64_t H, int ve, int lpr) { return (int)((H / ve + lpr - 1) / lpr); }
@@ -241,7 +246,7 @@ extern "C" int prl_rmsnorm_fwd(const void* x, int64_t x_row_stride, const void* 
   PRL_REQUIRE(x && w && y, "rmsnorm_fwd: x, w and y must not be NULL");
   const int es = dtype == PRL_F32 ? 4 : 2, ve = 16 / es;
   const int lpr = norm_lpr(H, ve), nv = norm_nv(H, ve, lpr);
-  const dim3 grid((unsigned)norm_blocks(rows, lpr)), block(kNormThreads);
+  const dim3 grid((unsigned)norm_blocks(rows, lpr, kNormFwdMaxBlocks)), block(kNormThreads);
   hipStream_t st = (hipStream_t)stream;
 #define PRL_FWD(DT, L, N, ...)                                                                                     \
   hipLaunchKernelGGL((k_rmsnorm_fwd<DT, L, N>), grid, block, 0, st, (const char*)x, x_row_stride * es, (const char*)w, \
@@ -280,9 +285,9 @@ extern "C" int prl_rmsnorm_bwd(const void* x, int64_t x_row_stride, const void* 
   PRL_CHECK_LAUNCH("rmsnorm_bwd");
   const dim3 fgrid((unsigned)((H + 31) / 32));
   if (dtype == PRL_BF16)
-    hipLaunchKernelGGL((k_colsum_finish<PRL_BF16>), fgrid, dim3(256), 0, st, part, nblk, (int)H, (char*)gw);
+    hipLaunchKernelGGL((k_colsum_finish<PRL_BF16>), fgrid, dim3(1024), 0, st, part, nblk, (int)H, (char*)gw);
   else
-    hipLaunchKernelGGL((k_colsum_finish<PRL_F32>), fgrid, dim3(256), 0, st, part, nblk, (int)H, (char*)gw);
+    hipLaunchKernelGGL((k_colsum_finish<PRL_F32>), fgrid, dim3(1024), 0, st, part, nblk, (int)H, (char*)gw);
   PRL_CHECK_LAUNCH("rmsnorm_bwd(finish)");
   return PRL_OK;
 }
