@@ -128,12 +128,13 @@ class Tensors(defaultdict):
         waits for that copy only, so a trainer can log step N while step N + 1 is
         already running.
 
-        With PRL_STATS_STREAM=1 the launches (and, with several ranks, the small
-        all-reduces between the passes) go to a stream of their own that first
-        waits for everything enqueued so far, so that the next step's kernels do
-        not queue behind them.  On one GPU that costs more than it hides (2.01 vs
-        1.97 ms per bench step: the cross-stream waits outweigh 45 us of
-        statistics), so the default is the current stream.  The pieces are
+        With several ranks the launches and the seven small all-reduces between
+        the passes go to a stream of their own that first waits for everything
+        enqueued so far, so that the next step's kernels do not queue behind
+        collectives whose cost is latency.  On one GPU there is nothing to hide
+        but 45 us of statistics and the cross-stream waits cost more than that
+        (2.01 vs 1.97 ms per bench step), so a single rank stays on the current
+        stream.  PRL_STATS_STREAM=1 / =0 forces either.  The pieces are
         referenced by the returned object until `result()` has been called."""
         keys = list(self.keys())
         if not keys:
@@ -159,7 +160,7 @@ class Tensors(defaultdict):
         C.check(lib.prl_stats_layout(n_keys, off), "prl_stats_layout")
         multi = dist.is_initialized() and dist.get_world_size() > 1
         main = torch.cuda.current_stream(dev)
-        side = _stats_stream(dev)
+        side = _stats_stream(dev, multi)
         if side is not None:
             side.wait_stream(main)  # the pieces were produced on the current stream
         with C.on_device(dev), (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
@@ -192,11 +193,13 @@ class Tensors(defaultdict):
 _STATS_STREAMS: dict[int, Any] = {}
 
 
-def _stats_stream(dev: torch.device):
-    """The per-device stream the statistics run on when asked to (default priority); None otherwise."""
+def _stats_stream(dev: torch.device, multi: bool):
+    """The per-device stream the statistics run on (default priority), or None for "the current stream":
+    their own stream when ranks exchange between the passes, unless PRL_STATS_STREAM says otherwise."""
     import os
 
-    if os.environ.get("PRL_STATS_STREAM", "0") != "1":
+    want = os.environ.get("PRL_STATS_STREAM", "auto")
+    if want == "0" or (want != "1" and not multi):
         return None
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     s = _STATS_STREAMS.get(idx)

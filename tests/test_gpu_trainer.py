@@ -207,10 +207,13 @@ def test_statistics_exchange_runs_over_rccl(monkeypatch):
                 return 2
 
         monkeypatch.setattr(U, "dist", LargerWorld())
-        exchanged = run()
-        assert exchanged.keys() == alone.keys()
-        for k in alone:
-            assert exchanged[k] == alone[k], k
+        for stream_choice in ("auto", "0"):  # with ranks to talk to, "auto" is a stream of the statistics' own
+            monkeypatch.setenv("PRL_STATS_STREAM", stream_choice)
+            exchanged = run()
+            assert exchanged.keys() == alone.keys()
+            for k in alone:
+                assert exchanged[k] == alone[k], (stream_choice, k)
+        assert U._STATS_STREAMS  # the stream was really made
     finally:
         dist.barrier()
         dist.destroy_process_group()
