@@ -90,18 +90,14 @@ def use_plan(plan: PackedPlan | None):
         _ACTIVE[0] = prev
 
 
-def no_mask() -> dict[str, None]:
-    """Pass as `attention_mask` to a transformers decoder to skip building the [T, T] mask (and the host
-    synchronisation inside its packed-row detection) when a plan is active."""
-    return {"full_attention": None, "sliding_attention": None}
-
-
 def packed_sdpa_attention(module: Any, query: Tensor, key: Tensor, value: Tensor, attention_mask: Tensor | None,
                           dropout: float = 0.0, scaling: float | None = None, **kwargs: Any):
     """Drop-in for transformers' `sdpa_attention_forward` (same arguments, same [batch, seq, heads, dim] result).
     Follows the active `PackedPlan`; without one, or for shapes the plan does not describe, the original runs."""
     plan = _ACTIVE[0]
-    if plan is None or query.shape[0] != 1 or query.shape[2] != plan.total or key.shape[2] != plan.total or dropout:
+    windowed = kwargs.get("sliding_window") is not None  # a sliding-window layer needs its own mask: not ours
+    if plan is None or windowed or query.shape[0] != 1 or query.shape[2] != plan.total \
+            or key.shape[2] != plan.total or dropout:
         return _HF_SDPA[0](module, query, key, value, attention_mask, dropout=dropout, scaling=scaling, **kwargs)
     n, lmax = plan.n, plan.lmax
     gqa = key.shape[1] != query.shape[1]

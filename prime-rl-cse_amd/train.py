@@ -33,7 +33,8 @@ def log(msg: str) -> None:
         print(msg, flush=True)
 
 
-def build_model(config: RLTrainerConfig, device: torch.device, mesh: Any, dtype: torch.dtype | None = None):
+def build_model(config: RLTrainerConfig, device: torch.device, mesh: Any, dtype: torch.dtype | None = None,
+                for_training: bool = True):
     mc = config.model
     attn = "sdpa"  # flash-attn is a CUDA package; PyTorch-ROCm's SDPA takes the packed rows' block-diagonal mask
     if Path(mc.name).is_dir():  # a local checkpoint directory in HF layout
@@ -63,7 +64,10 @@ def build_model(config: RLTrainerConfig, device: torch.device, mesh: Any, dtype:
                 model.model.layers.register_module(name, checkpoint_wrapper(block, preserve_rng_state=False))
     # `reshard_after_forward = true` is the reference's default and means "not asked for": models that fit stay
     # gathered for a whole step (trainer.keeps_parameters_gathered); `false` is honoured as given
-    T.setup_fsdp(model, mesh, DTYPES[mc.reduce_dtype], None if mc.reshard_after_forward else False)
+    # A model that only ever runs forwards (the logprob model) must reshard after each one: its weights are replaced
+    # between steps, and parameters left gathered would go on serving the old ones.
+    reshard = True if not for_training else (None if mc.reshard_after_forward else False)
+    T.setup_fsdp(model, mesh, DTYPES[mc.reduce_dtype], reshard)
     return model, cfg
 
 
@@ -108,7 +112,7 @@ def _train(config: RLTrainerConfig, world: Any, device: torch.device, mesh: Any)
     loader = FakeDataLoader(config.data.fake) if config.data.fake else DataLoader(config.output_dir, 0)
     logprob_model = None
     if config.recompute_logprobs:
-        logprob_model, _ = build_model(config, device, mesh, dtype=torch.bfloat16)
+        logprob_model, _ = build_model(config, device, mesh, dtype=torch.bfloat16, for_training=False)
         logprob_model.requires_grad_(False)
     snapshots: dict[int, dict[str, torch.Tensor]] = {}
     device_name = perf.describe_device(device)

@@ -217,3 +217,30 @@ def test_statistics_exchange_runs_over_rccl(monkeypatch):
     finally:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def test_logprob_model_serves_the_weights_it_was_last_given(monkeypatch):
+    """The forward-only model of the recompute pass gets new weights every step (train.py:205-214 of the
+    reference); what it computes must follow them even though nothing ever runs a backward through it."""
+    import torch.distributed as dist
+
+    from prime_rl_cse_amd import trainer as T
+    from prime_rl_cse_amd.settings import RLTrainerConfig
+    from prime_rl_cse_amd.train import build_model
+
+    _single_rank_env(monkeypatch, 29764)
+    dev = torch.device("cuda:0")
+    mesh = T.init_distributed(dev)
+    try:
+        cfg = RLTrainerConfig(model={"debug": {"num_layers": 1}})
+        model, _ = build_model(cfg, dev, mesh, dtype=torch.bfloat16, for_training=False)
+        model.requires_grad_(False)
+        mb = prl.FakeDataLoader(prl.FakeDataLoaderConfig(batch_size=2, micro_batch_size=2, seq_len=16)).get_batch()[0]
+        first = T.recompute_logprobs(model, [dict(mb)], dev)[0].clone()
+        state = {k: (v.detach().clone() * 0.5) for k, v in model.state_dict().items()}
+        model.load_state_dict(state)
+        second = T.recompute_logprobs(model, [dict(mb)], dev)[0]
+        assert not torch.equal(first, second)
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
