@@ -244,3 +244,38 @@ def test_logprob_model_serves_the_weights_it_was_last_given(monkeypatch):
     finally:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def test_once_per_step_collectives_give_the_per_micro_batch_gradients(monkeypatch):
+    """Parameters kept gathered and gradients reduce-scattered once per step (this package's arrangement for
+    models that fit) against resharding after every forward and reducing after every backward (the
+    reference's): same gradient norm, same updated weights."""
+    import torch.distributed as dist
+
+    _single_rank_env(monkeypatch, 29765)
+    dev = torch.device(DEV)
+    mesh = T.init_distributed(dev)
+    try:
+        cfg = tiny_config()
+        base = T.get_model(cfg, dev, torch.float32, seed=11)
+        gen = torch.Generator().manual_seed(6)
+        mbs = rows(gen, 4, [20, 12, 32], cfg.vocab_size)
+        out = {}
+        for name, reshard in (("per_micro_batch", True), ("once_per_step", None)):
+            model = copy.deepcopy(base)
+            T.setup_fsdp(model, mesh, reshard_after_forward=reshard, blocks_per_group=1 if reshard else None)
+            assert model._prl_keep_gathered == (reshard is None)
+            opt = torch.optim.SGD(model.parameters(), lr=0.5)
+            res = T.train_step(model, opt, mbs, prl.LossConfig(), max_norm=1e9, device=dev)
+            res2 = T.train_step(model, opt, mbs, prl.LossConfig(), max_norm=1e9, device=dev)  # weights must be fresh
+            out[name] = (res.grad_norm, res2.grad_norm,
+                         {k: v.full_tensor().clone() if hasattr(v, "full_tensor") else v.clone()
+                          for k, v in model.state_dict().items()})
+        a, b = out["per_micro_batch"], out["once_per_step"]
+        assert a[0] > 0 and abs(a[0] - b[0]) <= 1e-3 * a[0]
+        assert abs(a[1] - b[1]) <= 2e-3 * a[1] and abs(a[1] - a[0]) > 1e-6 * a[0]  # the second step saw new weights
+        for k in a[2]:
+            assert torch.allclose(a[2][k], b[2][k], rtol=1e-3, atol=1e-5), k
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
