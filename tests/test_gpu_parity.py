@@ -168,6 +168,32 @@ def test_response_lengths_long_rows_bit_exact():
     assert prl.get_response_lengths(pos.to(DEV)) == O.get_response_lengths(pos)
 
 
+def test_sample_boundaries_in_policy_loss_on_random_patterns():
+    """The single-workgroup bookkeeping kernel (rows up to 16384 tokens) and the multi-kernel one (longer rows)
+    against the oracle on position ids made of the patterns the boundary rule is sensitive to: runs of zeros,
+    0 1 restarts, lone zeros, restarts at the very end."""
+    gen = torch.Generator().manual_seed(31)
+    atoms = [[0], [0, 0], [0, 1], [0, 1, 2], [0, 1, 2, 3, 4], [1], [2, 0], [0, 0, 1], [5, 6], [0, 1, 0], [3]]
+    for trial in range(40):
+        n_atoms = int(torch.randint(1, 400, (1,), generator=gen))
+        seq = []
+        for k in torch.randint(0, len(atoms), (n_atoms,), generator=gen).tolist():
+            seq += atoms[k]
+        if trial % 10 == 0:  # a long row for the multi-kernel path
+            seq = seq * (16500 // max(len(seq), 1) + 1)
+        pos = torch.tensor(seq)
+        want = O.get_response_lengths(pos)
+        t = pos.numel()
+        x = torch.zeros(1, t, 8, device=DEV, dtype=torch.bfloat16)
+        z = torch.zeros(1, t, device=DEV)
+        _, aux = prl.policy_loss(x, torch.zeros(1, t, dtype=torch.long, device=DEV), pos[None].to(DEV), z, z,
+                                 torch.ones(1, t, dtype=torch.bool, device=DEV), 1.0, prl.LossConfig(), 1)
+        n = int(aux["n_seg"].item())
+        starts = aux["seg_start"][: n + 1].cpu()
+        assert (starts[1:] - starts[:-1]).tolist() == want, (trial, t)
+        assert prl.get_response_lengths(pos.to(DEV)) == want
+
+
 def test_advantages_against_reference_vectors():
     d = load_npz("advantages.npz")
     keys = sorted(k[: -len("__adv")] for k in d if k.endswith("__adv"))
