@@ -62,9 +62,11 @@ def parse() -> argparse.Namespace:
     p.add_argument("--no-trainer-extra", action="store_true",
                    help="at --gpus 1, do not append the short whole-trainer-step measurement to the line")
     p.add_argument("--trainer-steps", type=int, default=3)
-    p.add_argument("--trainer-impl", choices=["hf", "fused"], default="fused",
-                   help="whole-trainer-step workload: hf = the transformers blocks as they are; fused = their "
-                        "RMSNorm modules on this package's HIP kernels (the reference's model.impl = liger_kernel)")
+    p.add_argument("--trainer-impl", choices=["hf", "fused", "replica", "graphed"], default="fused",
+                   help="whole-trainer-step workload: hf = the transformers blocks as they are under FSDP2; fused = "
+                        "their RMSNorm / rotary / SwiGLU on this package's HIP kernels (the reference's model.impl = "
+                        "liger_kernel); replica = fused, the whole model on every GPU with sharded master weights; "
+                        "graphed = replica with every micro-batch replayed from a HIP graph")
     return p.parse_args()
 
 
@@ -185,26 +187,41 @@ def trainer_measure(dev, world: int, steps: int, warmup: int, cpu: bool, cpu_sec
     cfg = T.model_config("Qwen/Qwen3-0.6B")
     model = T.get_model(cfg, dev, torch.float32, seed=0)
     fused_modules = {}
-    if impl == "fused":
+    if impl != "hf":
         from prime_rl_cse_amd import fused
 
         fused_modules = fused.fuse_model(model)
-    T.setup_fsdp(model, mesh)
-    opt = T.setup_optimizer(model)
+    fsdp_groups = T.blocks_per_fsdp_group(model)
+    replica = None
+    if impl in ("graphed", "replica"):  # whole model per GPU, micro-batches from HIP graphs ("replica": eagerly)
+        from prime_rl_cse_amd.replica import Replica
+
+        replica = Replica(model, lambda m: torch.optim.AdamW(m.parameters(), lr=1e-6, weight_decay=0.01, fused=True),
+                          graphs=impl == "graphed")
+        opt = replica.optimizer
+
+        def step(mbs):
+            return replica.train_step(mbs, loss_cfg, samples=BATCH)
+    else:
+        T.setup_fsdp(model, mesh)
+        opt = T.setup_optimizer(model)
+
+        def step(mbs):
+            return T.train_step(model, opt, mbs, loss_cfg, device=dev, samples=BATCH)
     prl.reset_world()
     loader = prl.FakeDataLoader(prl.FakeDataLoaderConfig(batch_size=BATCH * world, micro_batch_size=MICRO_BATCH,
                                                          seq_len=SEQ_LEN))
     loss_cfg = prl.LossConfig()
     batches = [loader.get_batch() for _ in range(2)]
     for i in range(warmup):
-        T.train_step(model, opt, batches[i % 2], loss_cfg, device=dev, samples=BATCH)
+        step(batches[i % 2])
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     per_step = []
     t0 = time.perf_counter()
     for i in range(steps):
-        res = T.train_step(model, opt, batches[i % 2], loss_cfg, device=dev, samples=BATCH)
+        res = step(batches[i % 2])
         per_step.append(res.seconds)  # train_step ends with the statistics read, a host wait for the whole step
     torch.cuda.synchronize()
     if world > 1:
@@ -224,11 +241,18 @@ def trainer_measure(dev, world: int, steps: int, warmup: int, cpu: bool, cpu_sec
         "steps": steps,
         "loss": res.loss,
         "grad_norm": res.grad_norm,
-        "precision": "bf16 compute, fp32 master weights and gradient reduction (FSDP2 mixed precision), fp32 loss math",
+        "precision": "bf16 compute, fp32 master weights and gradient reduction, fp32 loss math",
         "attention": "sdpa",
         "blocks": "transformers Qwen3" + (f", modules on HIP kernels: {fused_modules}" if fused_modules else ""),
-        "fsdp_blocks_per_group": T.blocks_per_fsdp_group(model),
     }
+    if replica is None:
+        out["fsdp_blocks_per_group"] = fsdp_groups
+    else:
+        out["data_parallel"] = ("whole bf16 model and fp32 gradient sum per GPU, fp32 master weights and AdamW state "
+                                "sharded; one reduce-scatter and one all-gather per step")
+        out["micro_batches"] = {"replayed_from_hip_graphs": replica.replays, "run_eagerly": replica.eager_runs}
+        if replica.capture_errors:
+            out["capture_errors"] = list(replica.capture_errors.values())
     del model, opt
     torch.cuda.empty_cache()
     if cpu and world == 1:

@@ -263,6 +263,21 @@ int prl_swiglu_bwd(const void* gate, const void* up, const void* gout, void* gga
                    void* stream);
 
 /*
+ * Gradient accumulation over micro-batches into ONE flat fp32 buffer, one launch for all parameters:
+ *   acc[dst_offset[k] + i] += scale[0] * src[k][i]      for every tensor k, i < numel[k].
+ * Stands where FSDP2 sums every micro-batch's gradients in the fp32 reduce dtype
+ * (src/prime_rl/trainer/model.py:102-104; the micro-batch loop is src/prime_rl/trainer/rl/train.py:271-310).
+ * All arrays are DEVICE memory.  `src` holds one pointer per tensor (NULL: no gradient this time);
+ * chunk c covers elements [chunk_start[c], chunk_start[c] + prl_accumulate_chunk_elems()) of tensor
+ * chunk_tensor[c].  `scale` may be NULL (= 1); it is read on the device, so a captured launch can be
+ * replayed under another scale.  Chunks must not overlap in `acc`.
+ */
+int64_t prl_accumulate_chunk_elems(void);
+int prl_accumulate(const void* const* src, int src_dtype, const int64_t* dst_offset, const int64_t* numel,
+                   const int32_t* chunk_tensor, const int64_t* chunk_start, int64_t n_chunks, const float* scale,
+                   float* acc, void* stream);
+
+/*
  * Group-relative advantages: B rewards in consecutive groups of G.  Replaces
  * compute_advantages (src/prime_rl/orchestrator/advantage.py:71-103) for the
  * four kinds of its REGISTRY (:63-68).  `lengths` (int64 [B], completion

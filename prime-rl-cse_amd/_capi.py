@@ -70,6 +70,11 @@ SIGNATURES = {
     "prl_scale_rows_if_not_one": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "prl_swiglu_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     "prl_swiglu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
+    "prl_accumulate_chunk_elems": (c_int64, []),
+    "prl_accumulate": (
+        c_int,
+        [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p],
+    ),
     "prl_rope_supported": (c_int, [c_int, c_int64]),
     "prl_rope": (
         c_int,

@@ -16,13 +16,15 @@ from torch import nn
 from torch.optim.lr_scheduler import LambdaLR, LRScheduler
 
 
-def setup_optimizer(config: Any, model: nn.Module) -> torch.optim.Optimizer:
+def setup_optimizer(config: Any, model: nn.Module, fused: bool | None = None) -> torch.optim.Optimizer:
+    """The optimizer of src/prime_rl/trainer/optim.py:9-38 over `model.parameters()`.  `fused=True` asks torch for
+    its one-kernel AdamW (same update rule; worth it over one large flat parameter)."""
     if config.type == "sgd":
         return torch.optim.SGD(model.parameters(), lr=config.lr, weight_decay=config.weight_decay,
                                momentum=config.momentum, nesterov=config.nesterov)
     if config.type == "adamw":
         return torch.optim.AdamW(model.parameters(), lr=config.lr, weight_decay=config.weight_decay,
-                                 betas=(config.betas1, config.betas2))
+                                 betas=(config.betas1, config.betas2), **({} if fused is None else {"fused": fused}))
     if config.type == "muon":
         raise NotImplementedError("the Muon optimizer comes from the `dion` package, which is not installed here")
     raise ValueError(f"Invalid optimizer type: {config.type}")

@@ -1,0 +1,344 @@
+"""Data-parallel training of a model that fits whole on every MI355X, with each
+micro-batch replayed from a HIP graph.
+
+The reference shards every model with FSDP2 and, when `model.compile` is set,
+hands the blocks to a tracing compiler (src/prime_rl/trainer/model.py:102-135,
+:219-230).  For the models of its smaller recipes (0.6B .. 7B parameters) a
+288 GB GPU does not need the parameters sharded, and what limits the step is the
+HOST: a micro-batch is ~2500 kernel launches, and the GPU waits for Python a
+quarter of the time.  So here:
+
+  * every rank holds the whole model in bf16 in ONE flat buffer (the module's
+    parameters are views into it), and the whole fp32 gradient sum in another;
+  * the fp32 master weights and the optimizer state are sharded: rank r owns
+    elements [r * n / W, (r + 1) * n / W) of the flat buffer (what FSDP2's fp32
+    shards plus `MixedPrecisionPolicy(param_dtype=bf16, reduce_dtype=fp32)` are
+    in the reference);
+  * a micro-batch (forward, the HIP loss path, backward, gradient accumulation)
+    is captured once per input shape in a HIP graph and replayed: one launch
+    from the host instead of thousands.  Shapes seen for the first time, and
+    more distinct shapes than `max_graphs`, run eagerly through the same code;
+  * a step ends with ONE fp32 reduce-scatter (mean over ranks), the gradient
+    norm, the optimizer on the shard and ONE bf16 all-gather: the same traffic
+    as FSDP2 with parameters kept gathered, issued outside the graphs.
+
+The numbers that depend on the step (the loss normaliser) are read from device
+memory by the captured kernels, never baked into a graph.
+"""
+
+from __future__ import annotations
+
+import time
+from collections import OrderedDict
+from typing import Any
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch import Tensor, nn
+
+from . import _capi as C
+from .batch import to_device
+from .config import LossConfig
+from .data import MicroBatch
+from .loss import policy_loss, unit_gradient
+from .utils import Tensors
+
+ALIGN = 128  # elements: every parameter starts on a 256-byte boundary of the bf16 buffer
+
+
+def _round_up(n: int, a: int) -> int:
+    return (n + a - 1) // a * a
+
+
+class FlatState:
+    """The flat buffers of one rank and the end of a step over them (no HIP code in here: plain torch and
+    torch.distributed, so it also runs on the CPU over gloo).
+
+    `flat16`  [n]      compute copy of all parameters (the model's parameters are views into it)
+    `acc32`   [n]      this rank's gradient sum over the micro-batches of the step, fp32
+    `master`  [n / W]  this rank's shard of the fp32 master weights (an nn.Parameter: the optimizer's only one)
+    """
+
+    def __init__(self, model: nn.Module, group: Any = None, compute_dtype: torch.dtype = torch.bfloat16):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.params = list(model.parameters())
+        if not self.params:
+            raise ValueError("FlatState: the model has no parameters")
+        dev = self.params[0].device
+        self.numel = [p.numel() for p in self.params]
+        self.offsets, off = [], 0
+        for n in self.numel:
+            self.offsets.append(off)
+            off += _round_up(n, ALIGN)
+        self.total = _round_up(off, ALIGN * self.world)
+        self.shard = self.total // self.world
+        lo, hi = self.rank * self.shard, (self.rank + 1) * self.shard
+        self.flat16 = torch.zeros(self.total, dtype=compute_dtype, device=dev)
+        master = torch.zeros(self.shard, dtype=torch.float32, device=dev)
+        for p, o, n in zip(self.params, self.offsets, self.numel):
+            src = p.detach().reshape(-1)
+            self.flat16[o : o + n].copy_(src)
+            a, b = max(o, lo), min(o + n, hi)
+            if a < b:
+                master[a - lo : b - lo].copy_(src[a - o : b - o])
+            p.data = self.flat16[o : o + n].view(p.shape)  # the fp32 original is released here
+        self.master = nn.Parameter(master)
+        self.acc32 = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self._shard_grad = torch.zeros(self.shard, dtype=torch.float32, device=dev) if self.world > 1 else None
+        self._shard16 = torch.zeros(self.shard, dtype=compute_dtype, device=dev) if self.world > 1 else None
+
+    def holder(self) -> nn.Module:
+        """A module whose only parameter is the master shard: what the optimizer is built over.  AdamW and SGD
+        are element-wise, so one flat parameter takes exactly the steps the separate parameters would."""
+        return nn.ParameterList([self.master])
+
+    def _gloo(self) -> bool:
+        return dist.is_initialized() and dist.get_backend(self.group) == "gloo"
+
+    def finish_step(self, optimizer: torch.optim.Optimizer, max_norm: float | None) -> Tensor:
+        """Mean of the ranks' gradient sums, clip by the global norm, optimizer step on the shard, new compute
+        copy on every rank.  Returns the gradient norm before clipping (a 0-d tensor on the device; reading it
+        is the caller's one host synchronisation).  Same clipping rule as torch.nn.utils.clip_grad_norm_,
+        which the reference calls (src/prime_rl/trainer/rl/train.py:336-338)."""
+        if self.world > 1:
+            grad = self._shard_grad
+            if self._gloo():  # no reduce-scatter in gloo: reduce everything, keep the own part
+                dist.all_reduce(self.acc32, group=self.group)
+                lo = self.rank * self.shard
+                grad.copy_(self.acc32[lo : lo + self.shard]).div_(self.world)
+            else:
+                dist.reduce_scatter_tensor(grad, self.acc32, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            grad = self.acc32
+        sq = torch.linalg.vector_norm(grad, 2, dtype=torch.float32).square()
+        if self.world > 1:
+            dist.all_reduce(sq, group=self.group)
+        norm = sq.sqrt()
+        if max_norm is not None:
+            grad.mul_(torch.clamp(max_norm / (norm + 1e-6), max=1.0))
+        self.master.grad = grad
+        optimizer.step()
+        self.master.grad = None
+        if self.world > 1:
+            self._shard16.copy_(self.master.detach())
+            if self._gloo():
+                dist.all_gather(list(self.flat16.chunk(self.world)), self._shard16, group=self.group)
+            else:
+                dist.all_gather_into_tensor(self.flat16, self._shard16, group=self.group)
+        else:
+            self.flat16.copy_(self.master.detach())
+        self.acc32.zero_()
+        return norm
+
+
+class _Captured:
+    """One captured micro-batch shape: the graph, the buffers it reads and the tensors it leaves behind."""
+
+    def __init__(self) -> None:
+        self.graph: Any = None
+        self.inputs: dict[str, Tensor] = {}
+        self.plan: Any = None
+        self.loss: Tensor | None = None
+        self.aux: dict[str, Tensor] = {}
+        self.src: Tensor | None = None
+
+
+_TENSOR_KEYS = ("input_ids", "position_ids", "advantages", "logprobs", "loss_mask")
+_AUX_KEYS = ("logprobs", "entropy", "importance_ratio", "clipped_importance_ratio", "is_clipped")
+
+
+class Replica:
+    """The training side of one rank: model, flat state, optimizer and the micro-batch graphs."""
+
+    def __init__(self, model: nn.Module, optimizer_factory: Any, group: Any = None, graphs: bool = True,
+                 max_graphs: int = 4, compute_dtype: torch.dtype = torch.bfloat16):
+        """`model` on the GPU in any floating dtype (its values seed the fp32 master weights);
+        `optimizer_factory(module)` builds the optimizer over `module.parameters()`; `compute_dtype` is what
+        FSDP2's `param_dtype` is in the reference (bf16; fp32 for exact comparisons)."""
+        self.model = model
+        self.state = FlatState(model, group, compute_dtype)
+        self.device = self.state.flat16.device
+        if self.device.type != "cuda":
+            raise RuntimeError("Replica: the model must be on a GPU (there is no CPU path)")
+        self.optimizer = optimizer_factory(self.state.holder())
+        self.graphs = graphs
+        self.max_graphs = max_graphs
+        self._captured: "OrderedDict[tuple, _Captured]" = OrderedDict()
+        self._seen: set[tuple] = set()
+        self.capture_errors: dict[tuple, str] = {}
+        self._scale = torch.ones(1, dtype=torch.float32, device=self.device)
+        self.replays = 0
+        self.eager_runs = 0
+        # the chunk table of the accumulation kernel: parameter sizes never change
+        lib = C.load()
+        chunk = int(lib.prl_accumulate_chunk_elems())
+        st = self.state
+        tensor_of, start_of = [], []
+        for k, n in enumerate(st.numel):
+            starts = np.arange(0, n, chunk, dtype=np.int64)
+            tensor_of.append(np.full(starts.size, k, dtype=np.int32))
+            start_of.append(starts)
+        self._chunk_tensor = torch.from_numpy(np.concatenate(tensor_of)).to(self.device)
+        self._chunk_start = torch.from_numpy(np.concatenate(start_of)).to(self.device)
+        self._numel = torch.tensor(st.numel, dtype=torch.int64).to(self.device)
+        self._offsets = torch.tensor(st.offsets, dtype=torch.int64).to(self.device)
+        unit_gradient(self.device)  # exists before any capture
+
+    # ------------------------------------------------------------------ one micro-batch
+
+    def _forward_backward(self, mb: dict[str, Any], plan: Any, loss_config: LossConfig) -> tuple[Tensor, dict, list]:
+        from .trainer import forward
+
+        logits = forward(self.model, mb["input_ids"], mb["position_ids"], plan)
+        # normaliser 1 here: the step's own normaliser multiplies the gradients when they are accumulated
+        loss, aux = policy_loss(logits, mb["input_ids"], mb["position_ids"], mb["advantages"], mb["logprobs"],
+                                mb["loss_mask"], mb["temperature"], loss_config, 1.0, skip_masked=True)
+        del logits
+        loss.backward(unit_gradient(self.device))
+        grads = [p.grad for p in self.state.params]
+        return loss.detach(), aux, grads
+
+    def _grad_pointers(self, grads: list) -> list[int]:
+        dt = self.state.flat16.dtype
+        ptrs = []
+        for g, p in zip(grads, self.state.params):
+            if g is None:
+                ptrs.append(0)
+                continue
+            if g.dtype != dt or not g.is_contiguous() or g.numel() != p.numel():
+                raise RuntimeError("Replica: a gradient is not a dense tensor of the compute dtype")
+            ptrs.append(g.data_ptr())
+        return ptrs
+
+    def _accumulate(self, src: Tensor) -> None:
+        lib = C.load()
+        with C.on_device(self.device):
+            C.check(
+                lib.prl_accumulate(C.ptr(src), C.dtype_code(self.state.flat16), C.ptr(self._offsets),
+                                   C.ptr(self._numel), C.ptr(self._chunk_tensor), C.ptr(self._chunk_start),
+                                   self._chunk_tensor.numel(), C.ptr(self._scale), C.ptr(self.state.acc32),
+                                   C.stream_ptr(self.device)),
+                "prl_accumulate",
+            )
+
+    def _drop_grads(self) -> None:
+        for p in self.state.params:
+            p.grad = None
+
+    @staticmethod
+    def _key(mb: dict[str, Any], plan: Any, loss_config: LossConfig) -> tuple:
+        sig = None if plan is None else (plan.n, plan.lmax, plan.equal)
+        return (tuple(mb["input_ids"].shape), float(mb["temperature"]), sig, loss_config.ratio_type,
+                bool(loss_config.ratio_length_norm), float(loss_config.clip_ratio))
+
+    def _capture(self, mb: dict[str, Any], plan: Any, loss_config: LossConfig) -> _Captured:
+        cap = _Captured()
+        cap.inputs = {k: mb[k].clone() for k in _TENSOR_KEYS}
+        cap.inputs["temperature"] = mb["temperature"]
+        if plan is not None and not plan.equal:
+            import copy
+
+            cap.plan = copy.copy(plan)
+            cap.plan.gather, cap.plan.scatter = plan.gather.clone(), plan.scatter.clone()
+        else:
+            cap.plan = plan
+        cap.src = torch.zeros(len(self.state.params), dtype=torch.int64, device=self.device)
+        cap.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cap.graph):
+            cap.loss, cap.aux, grads = self._forward_backward(cap.inputs, cap.plan, loss_config)
+            ptrs = self._grad_pointers(grads)
+            self._accumulate(cap.src)
+            del grads
+            self._drop_grads()
+        # nothing has run yet: the graph reads this table when it is replayed
+        cap.src.copy_(torch.tensor(ptrs, dtype=torch.int64))
+        return cap
+
+    def micro_batch(self, mb: dict[str, Any], plan: Any, loss_config: LossConfig) -> tuple[Tensor, dict[str, Tensor]]:
+        """Forward, loss, backward and gradient accumulation of one row that is already on the device.
+        Returns the loss (for normaliser 1) and the per-token results, all safe to keep."""
+        key = self._key(mb, plan, loss_config)
+        cap = self._captured.get(key)
+        if cap is None and self.graphs and key in self._seen and key not in self.capture_errors:
+            try:
+                cap = self._capture(mb, plan, loss_config)
+            except RuntimeError as e:  # something in this shape's forward cannot be captured: it stays eager
+                self.capture_errors[key] = repr(e)
+                self._drop_grads()
+                cap = None
+            else:
+                self._captured[key] = cap
+                while len(self._captured) > self.max_graphs:
+                    self._captured.popitem(last=False)
+        self._seen.add(key)
+        if cap is not None:
+            self._captured.move_to_end(key)
+            for k in _TENSOR_KEYS:
+                cap.inputs[k].copy_(mb[k])
+            if cap.plan is not None and not cap.plan.equal:
+                cap.plan.gather.copy_(plan.gather)
+                cap.plan.scatter.copy_(plan.scatter)
+            cap.graph.replay()
+            self.replays += 1
+            return cap.loss.clone(), {k: cap.aux[k].clone() for k in _AUX_KEYS}
+        loss, aux, grads = self._forward_backward(mb, plan, loss_config)
+        src = torch.tensor(self._grad_pointers(grads), dtype=torch.int64).to(self.device)
+        self._accumulate(src)
+        del grads
+        self._drop_grads()
+        self.eager_runs += 1
+        return loss, aux
+
+    # ------------------------------------------------------------------ one optimizer step
+
+    def train_step(self, micro_batches: list[MicroBatch], loss_config: LossConfig, max_norm: float | None = 1.0,
+                   scheduler: Any = None, samples: int | None = None,
+                   recomputed_errors: list[Tensor] | None = None) -> Any:
+        """One optimizer step over this rank's micro-batches (src/prime_rl/trainer/rl/train.py:259-364);
+        same results and the same `StepResult` as `trainer.train_step`."""
+        from .trainer import StepResult, attention_plan, local_loss_scale
+
+        t0 = time.perf_counter()
+        inv_scale = 1.0 / max(float(local_loss_scale(micro_batches, loss_config)), 1.0)
+        self._scale.fill_(inv_scale)
+        tensors = Tensors()
+        tokens = 0
+        for step_idx, host_mb in enumerate(micro_batches):
+            mb = to_device(host_mb, self.device)
+            loss, aux = self.micro_batch(mb, attention_plan(host_mb, self.device), loss_config)
+            mask = mb["loss_mask"]
+            tensors.add("probs", aux["logprobs"], mask, exp=True)
+            tensors.add("old_probs", mb["logprobs"], mask, exp=True)
+            tensors.add("entropy", aux["entropy"], mask)
+            tensors.add("loss", (loss * inv_scale).reshape(1))
+            if recomputed_errors is not None:
+                tensors.add("recomputed_logprob_error", recomputed_errors[step_idx], mask)
+            if loss_config.ratio_type == "token":
+                for key in ("importance_ratio", "clipped_importance_ratio", "is_clipped"):
+                    tensors.add(key, aux[key], mask)
+            tokens += int(mb["input_ids"].numel())
+        grad_norm = self.state.finish_step(self.optimizer, max_norm)
+        if scheduler is not None:
+            scheduler.step()
+        stats = tensors.compute_stats()
+        seconds = time.perf_counter() - t0
+        if samples is None:
+            samples = len(micro_batches)
+        return StepResult(loss=stats.get("loss/mean", float("nan")), grad_norm=float(grad_norm), stats=stats,
+                          seconds=seconds, tokens=tokens, samples=samples)
+
+
+def eligible(model: nn.Module, optim_type: str, activation_checkpointing: bool = False) -> str | None:
+    """None when `Replica` can train this model, otherwise the reason it cannot (then FSDP2 does)."""
+    from .trainer import keeps_parameters_gathered
+
+    if not keeps_parameters_gathered(model):
+        return "the bf16 parameters do not fit the 32 GB a rank keeps whole"
+    if optim_type not in ("adamw", "sgd"):
+        return f"optimizer {optim_type!r} is not element-wise over a flat shard"
+    if activation_checkpointing:
+        return "activation checkpointing re-runs blocks inside backward"
+    return None

@@ -1,0 +1,170 @@
+"""`Replica` (whole model per GPU, micro-batches replayed from HIP graphs): the accumulation kernel against
+torch, a step against the same model on the CPU with the oracle's loss, and replayed graphs against the same
+code run eagerly, replay by replay, on data that changes every time."""
+
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+import prime_rl_cse_amd as prl
+from oracle import ref_cpu as O
+from prime_rl_cse_amd import _capi as C
+from prime_rl_cse_amd import trainer as T
+from prime_rl_cse_amd.replica import Replica, eligible
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def tiny_config(vocab=2048):
+    return T.model_config("Qwen/Qwen3-0.6B", num_layers=2, vocab_size=vocab, hidden_size=64, intermediate_size=128,
+                          num_attention_heads=4, num_key_value_heads=2, head_dim=16)
+
+
+def rows(gen, n_rows, lens, vocab):
+    out = []
+    for _ in range(n_rows):
+        t = sum(lens)
+        out.append({
+            "input_ids": torch.randint(0, vocab, (1, t), generator=gen),
+            "position_ids": torch.cat([torch.arange(n) for n in lens]).unsqueeze(0),
+            "advantages": torch.randn(1, t, generator=gen),
+            "logprobs": -8.0 + 0.3 * torch.randn(1, t, generator=gen),
+            "loss_mask": torch.rand(1, t, generator=gen) < 0.7,
+            "temperature": 0.9,
+        })
+    return out
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_accumulate_kernel_against_torch(dtype):
+    lib = C.load()
+    chunk = int(lib.prl_accumulate_chunk_elems())
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    sizes = [1, 7, 8, chunk - 3, chunk, chunk + 5, 3 * chunk + 1, 129]
+    offsets, off = [], 0
+    for n in sizes:
+        offsets.append(off)
+        off += (n + 127) // 128 * 128
+    srcs = [torch.randn(n, generator=gen, device=DEV).to(dtype) for n in sizes]
+    srcs[3] = None  # a parameter without a gradient
+    odd = torch.randn(sizes[7] + 1, generator=gen, device=DEV).to(dtype)
+    srcs[7] = odd[1:]  # not 16-byte aligned: the element-wise path
+    acc = torch.randn(off, generator=gen, device=DEV)
+    want = acc.clone()
+    scale = torch.tensor([0.37], device=DEV)
+    for s, o, n in zip(srcs, offsets, sizes):
+        if s is not None:
+            want[o : o + n] = torch.addcmul(want[o : o + n], s.float(), scale)
+    tensor_of = np.concatenate([np.full(len(range(0, n, chunk)), k, np.int32) for k, n in enumerate(sizes)])
+    start_of = np.concatenate([np.arange(0, n, chunk, dtype=np.int64) for n in sizes])
+    dev = lambda a: torch.from_numpy(a).to(DEV)
+    ptrs = torch.tensor([0 if s is None else s.data_ptr() for s in srcs], dtype=torch.int64).to(DEV)
+    numel, offs = torch.tensor(sizes).to(DEV), torch.tensor(offsets).to(DEV)
+    ct, cs = dev(tensor_of), dev(start_of)
+    for sc, expect in ((scale, want), (None, None)):
+        if sc is None:  # scale NULL means 1
+            expect = acc.clone()
+            for s, o, n in zip(srcs, offsets, sizes):
+                if s is not None:
+                    expect[o : o + n] += s.float()
+        got = acc.clone()
+        C.check(lib.prl_accumulate(C.ptr(ptrs), C.dtype_code(srcs[0]), C.ptr(offs), C.ptr(numel), C.ptr(ct), C.ptr(cs),
+                                   ct.numel(), C.ptr(sc), C.ptr(got), C.stream_ptr(torch.device(DEV))), "acc")
+        torch.cuda.synchronize()
+        torch.testing.assert_close(got, expect, rtol=1e-6, atol=1e-6)
+    assert lib.prl_accumulate(C.ptr(ptrs), 99, C.ptr(offs), C.ptr(numel), C.ptr(ct), C.ptr(cs), ct.numel(), None,
+                              C.ptr(acc), None) != 0
+
+
+@pytest.mark.parametrize("ratio_type", ["token", "sequence"])
+def test_fp32_replica_step_matches_cpu_model_with_oracle_loss(ratio_type):
+    cfg = tiny_config()
+    cpu_model = T.get_model(cfg, "cpu", torch.float32, seed=3)
+    gpu_model = copy.deepcopy(cpu_model).to(DEV)
+    gen = torch.Generator().manual_seed(5)
+    mbs = rows(gen, 4, [20, 12, 32], cfg.vocab_size)  # 4 rows of one shape: eager, capture + replay, replay, replay
+    loss_cfg = prl.LossConfig(ratio_type=ratio_type, clip_ratio=4.0)
+    scale = T.local_loss_scale(mbs, loss_cfg)
+    cpu_losses = []
+    for mb in mbs:
+        logits = T.forward(cpu_model, mb["input_ids"], mb["position_ids"])
+        x = O.shift_logits(logits.float().contiguous()) / mb["temperature"]
+        lp = O.selective_log_softmax(x, mb["input_ids"])
+        lens = O.get_response_lengths(mb["position_ids"])
+        loss, _ = O.compute_loss(lp.squeeze().split(lens), mb["logprobs"].squeeze().split(lens),
+                                 mb["advantages"].squeeze().split(lens), mb["loss_mask"].squeeze().split(lens),
+                                 O.LossConfig(ratio_type, False, 4.0), scale)
+        loss.backward()
+        cpu_losses.append(loss.item())
+    cpu_norm = torch.nn.utils.clip_grad_norm_(cpu_model.parameters(), 1e9).item()
+
+    rep = Replica(gpu_model, lambda m: torch.optim.SGD(m.parameters(), lr=1.0), compute_dtype=torch.float32)
+    before = rep.state.master.detach().clone()
+    res = rep.train_step(mbs, loss_cfg, max_norm=1e9)
+    assert rep.eager_runs == 1 and rep.replays == 3
+    assert abs(res.grad_norm - cpu_norm) <= 2e-4 * cpu_norm
+    assert abs(res.stats["loss/mean"] - sum(cpu_losses) / len(cpu_losses)) <= 1e-4
+    step = before - rep.state.master.detach()  # SGD with lr 1: the step is the gradient
+    for (name, p), o in zip(cpu_model.named_parameters(), rep.state.offsets):
+        ref = p.grad
+        got = step[o : o + ref.numel()].view(ref.shape).cpu()
+        assert torch.allclose(got, ref, rtol=2e-3, atol=2e-4 * ref.abs().max().item() + 1e-9), name
+    for p, o in zip(gpu_model.parameters(), rep.state.offsets):  # the model computes with the updated weights
+        assert torch.equal(p.detach().reshape(-1), rep.state.master.detach()[o : o + p.numel()])
+
+
+def _three_steps(graphs, batches, loss_cfg, max_graphs=4):
+    cfg = tiny_config(vocab=4096)
+    model = T.get_model(cfg, DEV, torch.float32, seed=11)
+    rep = Replica(model, lambda m: torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=0.01), graphs=graphs,
+                  max_graphs=max_graphs)
+    out = []
+    for mbs in batches:
+        res = rep.train_step(mbs, loss_cfg, max_norm=1.0)
+        out.append((res.grad_norm, res.stats, rep.state.flat16.clone(), rep.state.master.detach().clone()))
+    return rep, out
+
+
+@pytest.mark.parametrize("ratio_type", ["token", "sequence"])
+def test_replayed_graphs_match_eager_runs_on_changing_data(ratio_type):
+    gen = torch.Generator().manual_seed(9)
+    loss_cfg = prl.LossConfig(ratio_type=ratio_type)
+    # equal-length samples (side-by-side attention as a view), every micro-batch different data
+    batches = [rows(gen, 4, [32, 32, 32, 32], 4096) for _ in range(3)]
+    eager, want = _three_steps(False, batches, loss_cfg)
+    graphed, got = _three_steps(True, batches, loss_cfg)
+    assert eager.replays == 0 and graphed.eager_runs == 1 and graphed.replays == 11 and not graphed.capture_errors
+    for (n0, s0, f0, m0), (n1, s1, f1, m1) in zip(want, got):
+        assert n1 == pytest.approx(n0, rel=1e-5)
+        assert s1.keys() == s0.keys()
+        for k in s0:
+            assert s1[k] == pytest.approx(s0[k], rel=1e-5, abs=1e-7), k
+        torch.testing.assert_close(m1, m0, rtol=1e-5, atol=1e-7)
+        assert (f1 != f0).float().mean().item() < 1e-3  # bf16 copies: the odd rounding flip at most
+
+
+def test_ragged_rows_of_several_shapes_and_graph_eviction():
+    gen = torch.Generator().manual_seed(13)
+    loss_cfg = prl.LossConfig()
+    # one long sample (no side-by-side layout), ragged side-by-side twice with different index tables, equal lengths
+    shapes = [[40, 8, 8, 8], [20, 16, 16, 12], [16, 16, 16, 16], [20, 16, 16, 12], [12, 16, 16, 20], [40, 8, 8, 8]]
+    batches = [[rows(gen, 1, lens, 4096)[0] for lens in shapes] for _ in range(2)]
+    eager, want = _three_steps(False, batches, loss_cfg)
+    graphed, got = _three_steps(True, batches, loss_cfg, max_graphs=1)
+    assert graphed.replays > 0 and graphed.eager_runs >= 3 and len(graphed._captured) == 1
+    assert not graphed.capture_errors
+    for (n0, s0, f0, m0), (n1, s1, f1, m1) in zip(want, got):
+        assert n1 == pytest.approx(n0, rel=1e-5)
+        for k in s0:
+            assert s1[k] == pytest.approx(s0[k], rel=1e-5, abs=1e-7), k
+        torch.testing.assert_close(m1, m0, rtol=1e-5, atol=1e-7)
+
+
+def test_eligibility():
+    model = T.get_model(tiny_config(), "meta", torch.float32)
+    assert eligible(model, "adamw") is None and eligible(model, "sgd") is None
+    assert "element-wise" in eligible(model, "muon")
+    assert "checkpointing" in eligible(model, "adamw", activation_checkpointing=True)

@@ -1,0 +1,122 @@
+"""The flat parameter / gradient / master-weight buffers behind `Replica` and the end of a step over them:
+against torch's own clip_grad_norm_ + AdamW on separate fp32 parameters, on one rank and on two (gloo)."""
+
+import os
+
+import torch
+from torch import nn
+
+from prime_rl_cse_amd.replica import ALIGN, FlatState
+
+
+class Tiny(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(37, 19)  # sizes that are no multiple of anything
+        self.b = nn.Embedding(11, 37)
+        self.c = nn.Linear(19, 11, bias=False)
+        self.c.weight = nn.Parameter(self.c.weight)  # untied
+        self.tied = nn.Linear(37, 11, bias=False)
+        self.tied.weight = self.b.weight  # one parameter in two places, as embed_tokens / lm_head
+
+
+def _grads(seed: int, model: nn.Module) -> list[torch.Tensor]:
+    gen = torch.Generator().manual_seed(seed)
+    return [torch.randn(p.shape, generator=gen) * 3.0 for p in model.parameters()]
+
+
+def _expected(grads_per_rank: list[list[torch.Tensor]], steps: int, max_norm: float):
+    """Separate fp32 parameters, mean gradient over ranks, torch's clipping and AdamW."""
+    torch.manual_seed(0)
+    ref = Tiny()
+    params = list(ref.parameters())
+    opt = torch.optim.AdamW(params, lr=1e-2, weight_decay=0.01, betas=(0.9, 0.999))
+    norms = []
+    for s in range(steps):
+        for k, p in enumerate(params):
+            p.grad = sum(g[k] for g in grads_per_rank) / len(grads_per_rank) * (s + 1)
+        norms.append(float(torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm)))
+        opt.step()
+    return [p.detach() for p in params], norms
+
+
+def _run_steps(state: FlatState, model: nn.Module, my_grads: list[torch.Tensor], steps: int, max_norm: float):
+    opt = torch.optim.AdamW(state.holder().parameters(), lr=1e-2, weight_decay=0.01, betas=(0.9, 0.999))
+    norms = []
+    for s in range(steps):
+        for g, o, n in zip(my_grads, state.offsets, state.numel):
+            state.acc32[o : o + n] += g.reshape(-1) * (s + 1)
+        norms.append(float(state.finish_step(opt, max_norm)))
+        assert not state.acc32.any()  # cleared for the next step
+    return norms
+
+
+def test_flat_layout_and_one_rank_step():
+    torch.manual_seed(0)
+    model = Tiny()
+    before = [p.detach().clone() for p in model.parameters()]
+    assert len(before) == 4  # the tied weight counts once
+    state = FlatState(model)
+    assert state.world == 1 and state.total % ALIGN == 0 and all(o % ALIGN == 0 for o in state.offsets)
+    for p, b, o in zip(model.parameters(), before, state.offsets):
+        assert p.dtype == torch.bfloat16 and torch.equal(p, b.to(torch.bfloat16))
+        assert p.data_ptr() == state.flat16.data_ptr() + 2 * o  # a view into the flat buffer
+        assert torch.equal(state.master[o : o + b.numel()], b.reshape(-1))  # master weights keep fp32
+    assert model.tied.weight is model.b.weight
+    grads = _grads(1, model)
+    norms = _run_steps(state, model, grads, steps=3, max_norm=1.0)
+    want, want_norms = _expected([grads], steps=3, max_norm=1.0)
+    assert norms == __import__("pytest").approx(want_norms, rel=1e-5)
+    for p, w, o in zip(model.parameters(), want, state.offsets):
+        torch.testing.assert_close(state.master[o : o + w.numel()].view(w.shape), w, rtol=1e-5, atol=1e-6)
+        assert torch.equal(p, state.master[o : o + w.numel()].view(w.shape).to(torch.bfloat16))
+    # padding between parameters never moves
+    pad = torch.ones(state.total, dtype=torch.bool)
+    for o, n in zip(state.offsets, state.numel):
+        pad[o : o + n] = False
+    assert not state.master.detach()[pad].any() and not state.flat16[pad].any()
+
+
+def _rank(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        model = Tiny()
+        state = FlatState(model)
+        assert state.world == world and state.shard * world == state.total
+        norms = _run_steps(state, model, _grads(10 + rank, model), steps=2, max_norm=0.5)
+        q.put((rank, norms, [p.detach().float().tolist() for p in model.parameters()],
+               state.master.detach().tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_shard_master_weights_and_agree_over_gloo():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank, args=(r, 2, 29763, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    model = Tiny()
+    want, want_norms = _expected([_grads(10, model), _grads(11, model)], steps=2, max_norm=0.5)
+    import pytest
+
+    for rank, norms, params, master in res:
+        assert norms == pytest.approx(want_norms, rel=1e-5)
+        for got, w in zip(params, want):  # every rank ends with the same full bf16 copy
+            assert torch.equal(torch.tensor(got), w.to(torch.bfloat16).float())
+    # the two master shards, end to end, are the fp32 parameters
+    full = torch.tensor(res[0][3] + res[1][3])
+    state = FlatState(model)
+    for w, o in zip(want, state.offsets):
+        torch.testing.assert_close(full[o : o + w.numel()].view(w.shape), w, rtol=1e-5, atol=1e-6)
