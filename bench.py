@@ -62,7 +62,7 @@ def parse() -> argparse.Namespace:
     p.add_argument("--no-trainer-extra", action="store_true",
                    help="at --gpus 1, do not append the short whole-trainer-step measurement to the line")
     p.add_argument("--trainer-steps", type=int, default=3)
-    p.add_argument("--trainer-impl", choices=["hf", "fused", "replica", "graphed"], default="fused",
+    p.add_argument("--trainer-impl", choices=["hf", "fused", "replica", "graphed"], default="graphed",
                    help="whole-trainer-step workload: hf = the transformers blocks as they are under FSDP2; fused = "
                         "their RMSNorm / rotary / SwiGLU on this package's HIP kernels (the reference's model.impl = "
                         "liger_kernel); replica = fused, the whole model on every GPU with sharded master weights; "
@@ -172,7 +172,7 @@ def pmc_traffic(kernel: str, logits_dtype: str) -> tuple[float | None, str | Non
 
 
 def trainer_measure(dev, world: int, steps: int, warmup: int, cpu: bool, cpu_seconds: float,
-                    impl: str = "fused") -> dict:
+                    impl: str = "graphed") -> dict:
     """The whole optimizer step of the Qwen3-0.6B reverse_text recipe on synthetic rollouts: transformer body by
     PyTorch-ROCm (random init, bf16 compute under FSDP2, fp32 master weights and gradient reduction), everything
     after the LM head by this package, gradient clipping and AdamW (src/prime_rl/trainer/rl/train.py:259-352)."""

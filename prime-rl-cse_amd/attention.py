@@ -103,7 +103,7 @@ def packed_sdpa_attention(module: Any, query: Tensor, key: Tensor, value: Tensor
     gqa = key.shape[1] != query.shape[1]
 
     def side_by_side(x: Tensor) -> Tensor:  # [1, H, T, D] -> [n, H, lmax, D]
-        x = x[0]
+        x = x.squeeze(0)  # not x[0]: a select's backward is a zero fill plus a copy, a squeeze's is a view
         if not plan.equal:
             x = x.index_select(1, plan.gather)
         return x.unflatten(1, (n, lmax)).permute(1, 0, 2, 3)

@@ -33,29 +33,44 @@ def log(msg: str) -> None:
         print(msg, flush=True)
 
 
-def build_model(config: RLTrainerConfig, device: torch.device, mesh: Any, dtype: torch.dtype | None = None,
-                for_training: bool = True):
+def model_config_of(config: RLTrainerConfig) -> Any:
+    """The transformers config of `config.model`: read from a local checkpoint directory in HF layout, or made
+    from literal dimensions for the reference's model names (there is no hub access here)."""
     mc = config.model
-    attn = "sdpa"  # flash-attn is a CUDA package; PyTorch-ROCm's SDPA takes the packed rows' block-diagonal mask
-    if Path(mc.name).is_dir():  # a local checkpoint directory in HF layout
-        from transformers import AutoConfig, AutoModelForCausalLM
+    attn = "sdpa"  # flash-attn is a CUDA package; packed rows go through attention.py or SDPA's block-diagonal mask
+    if Path(mc.name).is_dir():
+        from transformers import AutoConfig
 
         cfg = AutoConfig.from_pretrained(mc.name)
         cfg._attn_implementation, cfg.use_cache = attn, False
         if mc.debug.num_layers is not None:
             cfg.num_hidden_layers = min(mc.debug.num_layers, cfg.num_hidden_layers)
+        return cfg
+    if mc.name in T.MODEL_DIMS:
+        return T.model_config(mc.name, attn=attn, num_layers=mc.debug.num_layers)
+    raise ValueError(f"model {mc.name!r} is neither a local directory nor one of {sorted(T.MODEL_DIMS)}")
+
+
+def build_model(config: RLTrainerConfig, device: torch.device, mesh: Any, dtype: torch.dtype | None = None,
+                for_training: bool = True, shard: bool = True):
+    """The model of `config.model` on `device`; `shard=False` leaves it whole (for `replica.Replica`, or as the
+    log-probability model beside one) instead of wrapping it in FSDP2."""
+    mc = config.model
+    cfg = model_config_of(config)
+    if Path(mc.name).is_dir():
+        from transformers import AutoModelForCausalLM
+
         model = AutoModelForCausalLM.from_pretrained(mc.name, config=cfg, dtype=dtype or DTYPES[mc.optimization_dtype])
         model.to(device)
-    elif mc.name in T.MODEL_DIMS:
-        cfg = T.model_config(mc.name, attn=attn, num_layers=mc.debug.num_layers)
+    else:
         model = T.get_model(cfg, device, dtype or DTYPES[mc.optimization_dtype])
         log(f"{mc.name}: no weights on this machine, training from a random initialisation")
-    else:
-        raise ValueError(f"model {mc.name!r} is neither a local directory nor one of {sorted(T.MODEL_DIMS)}")
     if mc.impl == "liger_kernel":  # the reference's switch for fused block kernels; here they are HIP kernels
         from .fused import fuse_model
 
         log(f"fused block kernels: {fuse_model(model)}")
+    if not shard:
+        return model, cfg
     if mc.ac is not None:
         from torch.distributed.algorithms._checkpoint.checkpoint_wrapper import checkpoint_wrapper
 
@@ -104,15 +119,33 @@ def train(config: RLTrainerConfig) -> list[dict[str, float]]:
 
 def _train(config: RLTrainerConfig, world: Any, device: torch.device, mesh: Any) -> list[dict[str, float]]:
     log(f"Starting RL trainer on {world}")
-    model, model_cfg = build_model(config, device, mesh)
-    optimizer = setup_optimizer(config.optim, model)
+    replica = None
+    if config.model.compile is not None:
+        # the reference's switch for torch.compile; here: the whole model on every GPU, every micro-batch replayed
+        # from a HIP graph (replica.py), for the models and optimizers that allows
+        from .replica import Replica, eligible
+
+        reason = eligible(T.get_model(model_config_of(config), "meta"), config.optim.type, config.model.ac is not None)
+        if reason is None:
+            model, model_cfg = build_model(config, device, mesh, shard=False)
+            fused = True if config.optim.type == "adamw" else None
+            replica = Replica(model, lambda m: setup_optimizer(config.optim, m, fused=fused))
+            log("model.compile: whole model per GPU, micro-batches replayed from HIP graphs")
+        else:
+            log(f"model.compile ignored ({reason}); FSDP2 as usual")
+    if replica is None:
+        model, model_cfg = build_model(config, device, mesh)
+        optimizer = setup_optimizer(config.optim, model)
+    else:
+        optimizer = replica.optimizer
     scheduler = setup_scheduler(optimizer, config.scheduler, config.max_steps, config.optim.lr)
     publisher = WeightPublisher(config.output_dir, config.weights.interval,
                                 config.ckpt.interval if config.ckpt else None, config.async_level, device)
     loader = FakeDataLoader(config.data.fake) if config.data.fake else DataLoader(config.output_dir, 0)
     logprob_model = None
     if config.recompute_logprobs:
-        logprob_model, _ = build_model(config, device, mesh, dtype=torch.bfloat16, for_training=False)
+        logprob_model, _ = build_model(config, device, mesh, dtype=torch.bfloat16, for_training=False,
+                                       shard=replica is None)
         logprob_model.requires_grad_(False)
     snapshots: dict[int, dict[str, torch.Tensor]] = {}
     device_name = perf.describe_device(device)
@@ -144,8 +177,12 @@ def _train(config: RLTrainerConfig, world: Any, device: torch.device, mesh: Any)
             t_recompute = time.perf_counter() - t0
         publisher.guard_parameters()
         samples = (config.data.fake.batch_size // world.world_size) if config.data.fake else None
-        res = T.train_step(model, optimizer, micro_batches, config.loss, config.optim.max_norm, device, scheduler,
-                           samples=samples, recomputed_errors=errors)
+        if replica is not None:
+            res = replica.train_step(micro_batches, config.loss, config.optim.max_norm, scheduler, samples=samples,
+                                     recomputed_errors=errors)
+        else:
+            res = T.train_step(model, optimizer, micro_batches, config.loss, config.optim.max_norm, device, scheduler,
+                               samples=samples, recomputed_errors=errors)
         publisher.maybe_clean(step)
         seq_len = micro_batches[0]["input_ids"].shape[1]
         if counter is None:

@@ -148,6 +148,34 @@ def test_trainer_entry_point_on_fake_data(tmp_path, monkeypatch):
     assert state["model.embed_tokens.weight"].shape == (151936, 1024)
 
 
+def test_trainer_entry_point_with_model_compile_replays_graphs(tmp_path, monkeypatch):
+    """`[model.compile]` selects the whole-model-per-GPU mode with micro-batches replayed from HIP graphs; the
+    run logs what the FSDP2 run of the same configuration logs."""
+    from prime_rl_cse_amd.settings import RLTrainerConfig, parse_argv
+    from prime_rl_cse_amd.train import train
+
+    base = ("max_steps = 3\nasync_level = 3\nrecompute_logprobs = true\n\n[data.fake]\nbatch_size = 8\n"
+            "micro_batch_size = 2\nseq_len = 64\n\n[model]\nimpl = \"liger_kernel\"\n\n[model.debug]\nnum_layers = 2\n")
+    runs = {}
+    for name, extra, port in (("fsdp", "", 29771), ("graphs", "\n[model.compile]\nfullgraph = false\n", 29772)):
+        _single_rank_env(monkeypatch, port)
+        toml = tmp_path / f"{name}.toml"
+        toml.write_text(base + extra)
+        cfg = parse_argv(RLTrainerConfig, ["@", str(toml), "--output-dir", str(tmp_path / name)], use_env=False)
+        assert (cfg.model.compile is not None) == (name == "graphs")
+        torch.manual_seed(0)  # the fake loader draws from the global generator
+        runs[name] = train(cfg)
+    for a, b in zip(runs["fsdp"], runs["graphs"]):
+        for key in ("loss/mean", "entropy/mean", "probs/mean", "importance_ratio/mean", "optim/grad_norm",
+                    "recomputed_logprob_error/mean"):
+            assert b[key] == pytest.approx(a[key], rel=2e-2, abs=1e-6), key
+    state = torch.load(tmp_path / "graphs" / "weights" / "step_3" / "pytorch_model.bin", weights_only=True)
+    want = torch.load(tmp_path / "fsdp" / "weights" / "step_3" / "pytorch_model.bin", weights_only=True)
+    assert state.keys() == want.keys()
+    for k in want:
+        assert state[k].dtype == want[k].dtype and state[k].shape == want[k].shape
+
+
 def test_trainer_entry_point_on_rollout_files(tmp_path, monkeypatch):
     """Fed by `rollouts/step_N/rank_0.pt` files as the orchestrator writes them
     (model: tests/integration/test_trainer_path.py:18-82 of the reference)."""
