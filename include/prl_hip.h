@@ -278,6 +278,30 @@ int prl_accumulate(const void* const* src, int src_dtype, const int64_t* dst_off
                    float* acc, void* stream);
 
 /*
+ * Causal self-attention over a packed row of SHORT samples (each at most 128 tokens, head dimension 128,
+ * bf16), hand-written for MFMA.  Stands where the reference's attention runs through flash-attn's
+ * variable-length kernel (`attn_implementation = "flash_attention_2"` with position ids that restart per
+ * sample, src/prime_rl/trainer/model.py:58-60, :251-254).
+ * Every tensor is [token][head][128] with the last dimension contiguous; `*_strides` = {token stride, head
+ * stride} in elements (HOST arrays).  `cu_seqlens` (DEVICE, int32 [n_samples + 1]) holds the first token of
+ * every sample and T at the end.  `lse2` (fp32 [q_heads][T]) receives the base-2 log-sum-exp of the scaled
+ * scores; the backward reads it, needs `delta` (fp32 [q_heads][T]) as scratch, and writes dq, dk, dv (tokens
+ * outside every sample are left untouched).  Samples longer than 128 tokens are the caller's to exclude
+ * (prl_attn_short_supported); a table that breaks the rule is clamped, never followed out of bounds.
+ */
+int prl_attn_short_supported(int dtype, int64_t head_dim, int64_t max_len, int64_t q_heads, int64_t kv_heads);
+int prl_attn_short_fwd(const void* q, const int64_t* q_strides, const void* k, const int64_t* k_strides,
+                       const void* v, const int64_t* v_strides, void* out, const int64_t* out_strides, float* lse2,
+                       const int32_t* cu_seqlens, int32_t n_samples, int64_t T, int32_t q_heads, int32_t kv_heads,
+                       float scale, void* stream);
+int prl_attn_short_bwd(const void* q, const int64_t* q_strides, const void* k, const int64_t* k_strides,
+                       const void* v, const int64_t* v_strides, const void* out, const int64_t* out_strides,
+                       const void* dout, const int64_t* dout_strides, const float* lse2, float* delta, void* dq,
+                       const int64_t* dq_strides, void* dk, const int64_t* dk_strides, void* dv,
+                       const int64_t* dv_strides, const int32_t* cu_seqlens, int32_t n_samples, int64_t T,
+                       int32_t q_heads, int32_t kv_heads, float scale, void* stream);
+
+/*
  * Group-relative advantages: B rewards in consecutive groups of G.  Replaces
  * compute_advantages (src/prime_rl/orchestrator/advantage.py:71-103) for the
  * four kinds of its REGISTRY (:63-68).  `lengths` (int64 [B], completion

@@ -75,6 +75,19 @@ SIGNATURES = {
         c_int,
         [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p],
     ),
+    "prl_attn_short_supported": (c_int, [c_int, c_int64, c_int64, c_int64, c_int64]),
+    "prl_attn_short_fwd": (
+        c_int,
+        [c_void_p, POINTER(c_int64), c_void_p, POINTER(c_int64), c_void_p, POINTER(c_int64), c_void_p,
+         POINTER(c_int64), c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_float, c_void_p],
+    ),
+    "prl_attn_short_bwd": (
+        c_int,
+        [c_void_p, POINTER(c_int64), c_void_p, POINTER(c_int64), c_void_p, POINTER(c_int64), c_void_p,
+         POINTER(c_int64), c_void_p, POINTER(c_int64), c_void_p, c_void_p, c_void_p, POINTER(c_int64), c_void_p,
+         POINTER(c_int64), c_void_p, POINTER(c_int64), c_void_p, c_int32, c_int64, c_int32, c_int32, c_float,
+         c_void_p],
+    ),
     "prl_rope_supported": (c_int, [c_int, c_int64]),
     "prl_rope": (
         c_int,

@@ -38,6 +38,8 @@ class PackedPlan:
     equal: bool  # every sample has lmax tokens
     gather: Tensor | None  # [n * lmax] row position feeding each padded slot (ragged rows only)
     scatter: Tensor | None  # [total] padded slot of each row position
+    cu: Tensor | None = None  # int32 [n + 1] on the device: first token of every sample, then `total` (lmax <= 128 only)
+    side_by_side: bool = True  # whether the padded layout at least halves the work of the masked row
 
 
 def sample_starts(position_ids: Tensor) -> np.ndarray:
@@ -58,21 +60,116 @@ def plan_from_position_ids(position_ids: Tensor, device: torch.device | str, max
     starts = sample_starts(position_ids)
     total = int(position_ids.numel())
     n = int(starts.size)
-    if n < 2:
+    if n == 0:
         return None
     lengths = np.diff(np.concatenate([starts, [total]]))
     lmax = int(lengths.max())
-    if n * lmax * lmax > max_work_ratio * total * total:
-        return None
+    cu = None
+    if lmax <= SHORT_MAX_LEN:
+        cu = torch.from_numpy(np.concatenate([starts, [total]]).astype(np.int32)).to(device, non_blocking=True)
+    side_by_side = n >= 2 and n * lmax * lmax <= max_work_ratio * total * total
+    if not side_by_side:
+        return None if cu is None else PackedPlan(total, n, lmax, False, None, None, cu, False)
     if bool((lengths == lmax).all()):
-        return PackedPlan(total, n, lmax, True, None, None)
+        return PackedPlan(total, n, lmax, True, None, None, cu)
     offs = np.arange(lmax, dtype=np.int64)[None, :]
     gather = starts[:, None] + np.minimum(offs, lengths[:, None] - 1)  # padding repeats the sample's last token
     seg = np.repeat(np.arange(n, dtype=np.int64), lengths)
     scatter = seg * lmax + (np.arange(total, dtype=np.int64) - starts[seg])
     g = torch.from_numpy(gather.reshape(-1)).to(device, non_blocking=True)
-    s = torch.from_numpy(scatter).to(device, non_blocking=True)
-    return PackedPlan(total, n, lmax, False, g, s)
+    sc = torch.from_numpy(scatter).to(device, non_blocking=True)
+    return PackedPlan(total, n, lmax, False, g, sc, cu)
+
+
+SHORT_MAX_LEN = 128  # longest sample the short-sample kernels take (and the only head dimension: 128)
+
+
+def _short_kernel_enabled() -> bool:
+    """PRL_ATTN_SHORT=0 sends short samples through SDPA too (for A/B measurements)."""
+    import os
+
+    return os.environ.get("PRL_ATTN_SHORT", "1") != "0"
+
+
+def _strides2(x: Tensor):
+    from . import _capi as C
+
+    return (C.c_int64 * 2)(x.stride(2), x.stride(1))  # [1, heads, tokens, d] view: token stride, head stride
+
+
+def _kernel_ready(x: Tensor) -> Tensor:
+    """[1, heads, tokens, d] with d contiguous, 16-byte aligned, strides in multiples of 8 elements; else a copy."""
+    if x.stride(3) != 1 or x.data_ptr() % 16 or x.stride(1) % 8 or x.stride(2) % 8:
+        return x.contiguous()
+    return x
+
+
+class _AttnShort(torch.autograd.Function):
+    """q [1, Hq, T, 128], k / v [1, Hkv, T, 128] (any token / head strides) -> out [1, T, Hq, 128]."""
+
+    @staticmethod
+    def forward(ctx, q: Tensor, k: Tensor, v: Tensor, cu: Tensor, n: int, scale: float):
+        from . import _capi as C
+
+        dev = C.require_device(q, k, v, cu)
+        lib = C.load()
+        q, k, v = _kernel_ready(q), _kernel_ready(k), _kernel_ready(v)
+        _, hq, t, d = q.shape
+        hkv = k.shape[1]
+        out = torch.empty((1, t, hq, d), dtype=q.dtype, device=dev)
+        lse2 = torch.empty((hq, t), dtype=torch.float32, device=dev)
+        ov = out.transpose(1, 2)
+        with C.on_device(dev), C.timed("prl_attn_short_fwd", dev):
+            C.check(
+                lib.prl_attn_short_fwd(C.ptr(q), _strides2(q), C.ptr(k), _strides2(k), C.ptr(v), _strides2(v),
+                                       C.ptr(out), _strides2(ov), C.ptr(lse2), C.ptr(cu), n, t, hq, hkv, scale,
+                                       C.stream_ptr(dev)),
+                "prl_attn_short_fwd",
+            )
+        ctx.save_for_backward(q, k, v, out, lse2, cu)
+        ctx.n, ctx.scale = n, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: Tensor):
+        from . import _capi as C
+
+        q, k, v, out, lse2, cu = ctx.saved_tensors
+        dev = q.device
+        lib = C.load()
+        _, hq, t, d = q.shape
+        hkv = k.shape[1]
+        do = _kernel_ready(dout.transpose(1, 2))
+        ov = out.transpose(1, 2)
+        dq = torch.empty((1, t, hq, d), dtype=q.dtype, device=dev).transpose(1, 2)
+        dk = torch.empty((1, t, hkv, d), dtype=q.dtype, device=dev).transpose(1, 2)
+        dv = torch.empty((1, t, hkv, d), dtype=q.dtype, device=dev).transpose(1, 2)
+        delta = torch.empty((hq, t), dtype=torch.float32, device=dev)
+        with C.on_device(dev), C.timed("prl_attn_short_bwd", dev):
+            C.check(
+                lib.prl_attn_short_bwd(C.ptr(q), _strides2(q), C.ptr(k), _strides2(k), C.ptr(v), _strides2(v),
+                                       C.ptr(ov), _strides2(ov), C.ptr(do), _strides2(do), C.ptr(lse2), C.ptr(delta),
+                                       C.ptr(dq), _strides2(dq), C.ptr(dk), _strides2(dk), C.ptr(dv), _strides2(dv),
+                                       C.ptr(cu), ctx.n, t, hq, hkv, ctx.scale, C.stream_ptr(dev)),
+                "prl_attn_short_bwd",
+            )
+        return dq, dk, dv, None, None, None
+
+
+def short_attention_supported(query: Tensor, key: Tensor, plan: "PackedPlan") -> bool:
+    if plan.cu is None or not query.is_cuda or query.dtype != torch.bfloat16 or not _short_kernel_enabled():
+        return False
+    from . import _capi as C
+
+    return bool(C.load().prl_attn_short_supported(C.dtype_code(query), query.shape[3], plan.lmax, query.shape[1],
+                                                  key.shape[1]))
+
+
+def short_attention(query: Tensor, key: Tensor, value: Tensor, plan: "PackedPlan", scaling: float | None = None):
+    """Causal attention within every sample of a packed row of short samples; [1, heads, T, 128] in,
+    [1, T, heads, 128] out (the layout transformers' attention functions return)."""
+    scale = float(scaling) if scaling is not None else float(query.shape[3]) ** -0.5
+    return _AttnShort.apply(query, key, value, plan.cu, plan.n, scale)
 
 
 _ACTIVE: list[PackedPlan | None] = [None]
@@ -98,6 +195,10 @@ def packed_sdpa_attention(module: Any, query: Tensor, key: Tensor, value: Tensor
     windowed = kwargs.get("sliding_window") is not None  # a sliding-window layer needs its own mask: not ours
     if plan is None or windowed or query.shape[0] != 1 or query.shape[2] != plan.total \
             or key.shape[2] != plan.total or dropout:
+        return _HF_SDPA[0](module, query, key, value, attention_mask, dropout=dropout, scaling=scaling, **kwargs)
+    if short_attention_supported(query, key, plan):
+        return short_attention(query, key, value, plan, scaling), None
+    if not plan.side_by_side:
         return _HF_SDPA[0](module, query, key, value, attention_mask, dropout=dropout, scaling=scaling, **kwargs)
     n, lmax = plan.n, plan.lmax
     gqa = key.shape[1] != query.shape[1]

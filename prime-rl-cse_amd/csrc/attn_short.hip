@@ -1,0 +1,477 @@
+// Causal self-attention over a packed row whose samples are SHORT (at most 128 tokens, head dimension 128):
+// the rows of the reference's reverse_text recipe (seq_len 128) and of any recipe with short completions.
+// The reference gets its attention from flash-attn's variable-length kernel through transformers
+// (`attn_implementation = "flash_attention_2"`, src/prime_rl/trainer/model.py:58-60, :251-254); flash-style
+// kernels tile long sequences, and on 256 sequences of 128 tokens they are bound by their own latency
+// (49 us forward, 77 us backward per layer measured with PyTorch-ROCm's on this row shape).  A sample this
+// short needs no tiling at all: its whole K and V fit the LDS of one compute unit, the whole score matrix
+// of one head fits the registers of four waves, and the soft-max is a plain two-pass one.
+//
+// Forward: one workgroup (4 waves) per (sample, query head); wave w owns queries 32w .. 32w+31 and, the
+// mask being causal, key tiles 0 .. w.  Scores are computed TRANSPOSED (S^T = K Q^T, MFMA 32x32x16 bf16):
+// the query then sits on the lane and the keys in the accumulator registers, so row maxima and sums are
+// in-register reductions plus one exchange between the two lane halves, and the accumulators are already
+// the B operand of O^T = V^T P^T (rows of an accumulator tile = the k index of the next product).
+// Backward: two kernels.  `dq` has the forward's shape (S^T, dP^T = V dO^T, dS^T, dQ^T = K^T dS^T); `dkv`
+// runs one workgroup per (sample, key/value head), wave w owning keys 32w .. 32w+31, with the key on the
+// lane (S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS) and sums over the query heads of the group
+// in registers, so nothing is added across workgroups and nothing needs an atomic.
+// Operands that a product consumes along the token index (V in the forward, K, Q and dO in the backward)
+// are staged into LDS transposed, [d][token].
+#include "prl_common.h"
+
+namespace prl {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kAL = 128;     // longest sample
+constexpr int kAD = 128;     // head dimension
+constexpr int kAP = 136;     // LDS row pitch in elements: 272 B, a multiple of 16
+constexpr int kAImg = kAL * kAP;  // elements of one [128][128] image
+constexpr int kAThreads = 256;
+
+struct AttnView {  // one [token][head][d] tensor of 16-bit elements, d contiguous
+  const uint16_t* p;
+  int64_t ts, hs;  // strides in elements
+};
+
+__device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x8 as_frag(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+// accumulator registers 8s .. 8s+7 of a tile as the operand fragment of k-step s of the next product
+__device__ __forceinline__ bf16x8 acc_frag(const f32x16& x, int s) {
+  u32x4 v;
+  v.x = pack_bf16(x[8 * s + 0], x[8 * s + 1]);
+  v.y = pack_bf16(x[8 * s + 2], x[8 * s + 3]);
+  v.z = pack_bf16(x[8 * s + 4], x[8 * s + 5]);
+  v.w = pack_bf16(x[8 * s + 6], x[8 * s + 7]);
+  return as_frag(v);
+}
+// row of an accumulator tile that register i of lane half h holds
+__device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+// rows [0, len) of one head, tokens start .. start+len-1, into a natural [token][d] image; other rows zero
+__device__ __forceinline__ void stage_rows(uint16_t* img, const AttnView& x, int64_t start, int len, int head) {
+#pragma unroll
+  for (int it = 0; it < kAL * kAD / 8 / kAThreads; ++it) {
+    const int id = it * kAThreads + threadIdx.x, tok = id >> 4, ch = id & 15;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (tok < len) v = *reinterpret_cast<const u32x4*>(x.p + (start + tok) * x.ts + head * x.hs + ch * 8);
+    *reinterpret_cast<u32x4*>(img + tok * kAP + ch * 8) = v;
+  }
+}
+// the same rows into a transposed [d][token] image
+__device__ __forceinline__ void stage_transposed(uint16_t* img, const AttnView& x, int64_t start, int len, int head) {
+  const int tok = threadIdx.x & (kAL - 1), half = threadIdx.x >> 7;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ch = half * 8 + j;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (tok < len) v = *reinterpret_cast<const u32x4*>(x.p + (start + tok) * x.ts + head * x.hs + ch * 8);
+    uint16_t* col = img + (ch * 8) * kAP + tok;
+    col[0 * kAP] = (uint16_t)v.x, col[1 * kAP] = (uint16_t)(v.x >> 16);
+    col[2 * kAP] = (uint16_t)v.y, col[3 * kAP] = (uint16_t)(v.y >> 16);
+    col[4 * kAP] = (uint16_t)v.z, col[5 * kAP] = (uint16_t)(v.z >> 16);
+    col[6 * kAP] = (uint16_t)v.w, col[7 * kAP] = (uint16_t)(v.w >> 16);
+  }
+}
+// fragment of a natural image for a product that sums over d: row `row`, d = 16 kk + 8 h .. + 7
+__device__ __forceinline__ bf16x8 frag_rows(const uint16_t* img, int row, int kk, int h) {
+  return as_frag(*reinterpret_cast<const u32x4*>(img + row * kAP + 16 * kk + 8 * h));
+}
+// fragment of a transposed image for a product whose other operand is an accumulator tile: row `row` (a d),
+// tokens tok0 + 16 s + 8 (j >> 2) + 4 h + (j & 3) in element j
+__device__ __forceinline__ bf16x8 frag_cols(const uint16_t* img, int row, int tok0, int s, int h) {
+  const uint16_t* p = img + row * kAP + tok0 + 16 * s + 4 * h;
+  const u32x2 lo = *reinterpret_cast<const u32x2*>(p), hi = *reinterpret_cast<const u32x2*>(p + 8);
+  u32x4 v = {lo.x, lo.y, hi.x, hi.y};
+  return as_frag(v);
+}
+// the same fragment of a row read from global memory (token `tok` of the sample, or zeros past its end)
+__device__ __forceinline__ bf16x8 frag_global(const AttnView& x, int64_t start, int len, int head, int tok, int kk,
+                                              int h) {
+  u32x4 v = {0u, 0u, 0u, 0u};
+  if (tok < len) v = *reinterpret_cast<const u32x4*>(x.p + (start + tok) * x.ts + head * x.hs + 16 * kk + 8 * h);
+  return as_frag(v);
+}
+
+__device__ __forceinline__ void sample_range(const int32_t* cu, int s, int64_t T, int64_t& start, int& len) {
+  int64_t a = cu[s], b = cu[s + 1];
+  if (a < 0) a = 0;
+  if (b > T) b = T;
+  int64_t n = b - a;
+  if (n < 0) n = 0;
+  if (n > kAL) n = kAL;  // the host checks the lengths; this only keeps a bad table inside the buffers
+  start = a;
+  len = (int)n;
+}
+
+// lse2 is the base-2 log-sum-exp of the scaled scores, [head][token]
+__global__ __launch_bounds__(kAThreads) void k_attn_short_fwd(AttnView q, AttnView k, AttnView v, uint16_t* o,
+                                                              int64_t o_ts, int64_t o_hs, float* lse2,
+                                                              const int32_t* cu, int Hq, int G, int64_t T, float c) {
+  extern __shared__ __align__(16) uint16_t lds[];
+  uint16_t* Ks = lds;
+  uint16_t* Vt = lds + kAImg;
+  const int s = blockIdx.x / Hq, hq = blockIdx.x % Hq, hkv = hq / G;
+  int64_t start;
+  int len;
+  sample_range(cu, s, T, start, len);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int query = 32 * w + r;
+  bf16x8 qf[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) qf[kk] = frag_global(q, start, len, hq, query, kk, h);
+  stage_rows(Ks, k, start, len, hkv);
+  stage_transposed(Vt, v, start, len, hkv);
+  __syncthreads();
+  int ntile = (len + 31) >> 5;
+  if (ntile > w + 1) ntile = w + 1;  // causal: no key tile beyond the wave's own queries
+  if (32 * w >= len) return;         // no query of this wave exists (after the only barrier)
+
+  f32x16 st[4];
+  float m = -INFINITY;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    if (mt < ntile) {
+      f32x16 acc = {};
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) acc = mfma(frag_rows(Ks, 32 * mt + r, kk, h), qf[kk], acc);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int key = 32 * mt + acc_row(i, h);
+        const float sv = (key <= query && key < len) ? acc[i] : -INFINITY;
+        acc[i] = sv;
+        m = fmaxf(m, sv);
+      }
+      st[mt] = acc;
+    }
+  }
+  m = fmaxf(m, __shfl_xor(m, 32, kWave));  // key 0 is never masked, so m is finite
+  float l = 0.0f;
+  const float mc = m * c;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    if (mt < ntile) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(st[mt][i], c, -mc));  // c > 0: a masked score stays -inf, p = 0
+        st[mt][i] = p;
+        l += p;
+      }
+    }
+  }
+  l += __shfl_xor(l, 32, kWave);
+
+  f32x16 ot[4] = {};
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    if (mt < ntile) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pf = acc_frag(st[mt], s2);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) ot[dt] = mfma(frag_cols(Vt, 32 * dt + r, 32 * mt, s2, h), pf, ot[dt]);
+      }
+    }
+  }
+  if (query < len) {
+    const float inv = 1.0f / l;
+    uint16_t* orow = o + (start + query) * o_ts + hq * o_hs;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 pk;
+        pk.x = pack_bf16(ot[dt][4 * g + 0] * inv, ot[dt][4 * g + 1] * inv);
+        pk.y = pack_bf16(ot[dt][4 * g + 2] * inv, ot[dt][4 * g + 3] * inv);
+        *reinterpret_cast<u32x2*>(orow + 32 * dt + 8 * g + 4 * h) = pk;
+      }
+    }
+    if (h == 0) lse2[(int64_t)hq * T + start + query] = mc + __builtin_amdgcn_logf(l);
+  }
+}
+
+// dQ, and delta = rowsum(dO * O) [head][token] for the dK / dV kernel
+__global__ __launch_bounds__(kAThreads) void k_attn_short_bwd_dq(AttnView q, AttnView k, AttnView v, AttnView o,
+                                                                 AttnView dout, const float* lse2, float* delta,
+                                                                 uint16_t* dq, int64_t dq_ts, int64_t dq_hs,
+                                                                 const int32_t* cu, int Hq, int G, int64_t T,
+                                                                 float c, float scale) {
+  extern __shared__ __align__(16) uint16_t lds[];
+  uint16_t* Ks = lds;
+  uint16_t* Vs = lds + kAImg;
+  uint16_t* Kt = lds + 2 * kAImg;
+  const int s = blockIdx.x / Hq, hq = blockIdx.x % Hq, hkv = hq / G;
+  int64_t start;
+  int len;
+  sample_range(cu, s, T, start, len);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int query = 32 * w + r;
+  bf16x8 qf[8], dof[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) {
+    qf[kk] = frag_global(q, start, len, hq, query, kk, h);
+    dof[kk] = frag_global(dout, start, len, hq, query, kk, h);
+  }
+  // delta of the lane's query: this lane's 8 of every 16 d, then the other half's
+  float dl = 0.0f;
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) {
+    const bf16x8 of = frag_global(o, start, len, hq, query, kk, h);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dl = fmaf((float)dof[kk][j], (float)of[j], dl);
+  }
+  dl += __shfl_xor(dl, 32, kWave);
+  float ls = 0.0f;
+  if (query < len) {
+    ls = lse2[(int64_t)hq * T + start + query];
+    if (h == 0) delta[(int64_t)hq * T + start + query] = dl;
+  }
+  stage_rows(Ks, k, start, len, hkv);
+  stage_rows(Vs, v, start, len, hkv);
+  stage_transposed(Kt, k, start, len, hkv);
+  __syncthreads();
+  int ntile = (len + 31) >> 5;
+  if (ntile > w + 1) ntile = w + 1;
+  if (32 * w >= len) return;
+
+  f32x16 dqt[4] = {};
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    if (mt < ntile) {
+      f32x16 sa = {}, dp = {};
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        sa = mfma(frag_rows(Ks, 32 * mt + r, kk, h), qf[kk], sa);
+        dp = mfma(frag_rows(Vs, 32 * mt + r, kk, h), dof[kk], dp);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int key = 32 * mt + acc_row(i, h);
+        const bool valid = key <= query && key < len && query < len;
+        const float p = valid ? __builtin_amdgcn_exp2f(fmaf(sa[i], c, -ls)) : 0.0f;
+        sa[i] = p * (dp[i] - dl) * scale;  // dS^T
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 df = acc_frag(sa, s2);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dqt[dt] = mfma(frag_cols(Kt, 32 * dt + r, 32 * mt, s2, h), df, dqt[dt]);
+      }
+    }
+  }
+  if (query < len) {
+    uint16_t* row = dq + (start + query) * dq_ts + hq * dq_hs;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 pk;
+        pk.x = pack_bf16(dqt[dt][4 * g + 0], dqt[dt][4 * g + 1]);
+        pk.y = pack_bf16(dqt[dt][4 * g + 2], dqt[dt][4 * g + 3]);
+        *reinterpret_cast<u32x2*>(row + 32 * dt + 8 * g + 4 * h) = pk;
+      }
+    }
+  }
+}
+
+// dK and dV of one (sample, key/value head), summed over the G query heads that share it
+__global__ __launch_bounds__(kAThreads) void k_attn_short_bwd_dkv(AttnView q, AttnView k, AttnView v, AttnView dout,
+                                                                  const float* lse2, const float* delta,
+                                                                  uint16_t* dk, int64_t dk_ts, int64_t dk_hs,
+                                                                  uint16_t* dv, int64_t dv_ts, int64_t dv_hs,
+                                                                  const int32_t* cu, int Hkv, int G, int64_t T,
+                                                                  float c, float scale) {
+  extern __shared__ __align__(16) uint16_t lds[];
+  uint16_t* Qs = lds;
+  uint16_t* Os = lds + kAImg;      // dO, natural
+  uint16_t* Qt = lds + 2 * kAImg;
+  uint16_t* Ot = lds + 3 * kAImg;  // dO, transposed
+  float* row_lse = reinterpret_cast<float*>(lds + 4 * kAImg);
+  float* row_delta = row_lse + kAL;
+  const int s = blockIdx.x / Hkv, hkv = blockIdx.x % Hkv;
+  int64_t start;
+  int len;
+  sample_range(cu, s, T, start, len);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int key = 32 * w + r;
+  bf16x8 kf[8], vf[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) {
+    kf[kk] = frag_global(k, start, len, hkv, key, kk, h);
+    vf[kk] = frag_global(v, start, len, hkv, key, kk, h);
+  }
+  const int qtiles = (len + 31) >> 5;
+  f32x16 dkt[4] = {}, dvt[4] = {};
+  for (int g = 0; g < G; ++g) {
+    const int hq = hkv * G + g;
+    __syncthreads();  // the previous head's images are no longer read
+    stage_rows(Qs, q, start, len, hq);
+    stage_rows(Os, dout, start, len, hq);
+    stage_transposed(Qt, q, start, len, hq);
+    stage_transposed(Ot, dout, start, len, hq);
+    if (threadIdx.x < kAL) {
+      const bool in = (int)threadIdx.x < len;
+      row_lse[threadIdx.x] = in ? lse2[(int64_t)hq * T + start + threadIdx.x] : 0.0f;
+      row_delta[threadIdx.x] = in ? delta[(int64_t)hq * T + start + threadIdx.x] : 0.0f;
+    }
+    __syncthreads();
+    if (32 * w < len) {  // wave-uniform: this wave has keys
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {  // query tiles; causal: only those at or after the wave's keys
+        if (mt >= w && mt < qtiles) {
+          f32x16 sa = {}, dp = {};
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) {
+            sa = mfma(frag_rows(Qs, 32 * mt + r, kk, h), kf[kk], sa);  // S: rows = queries, lane = key
+            dp = mfma(frag_rows(Os, 32 * mt + r, kk, h), vf[kk], dp);  // dP = dO V^T
+          }
+          f32x16 pa, ds;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int query = 32 * mt + acc_row(i, h);
+            const bool valid = key <= query && query < len && key < len;
+            const float p = valid ? __builtin_amdgcn_exp2f(fmaf(sa[i], c, -row_lse[query])) : 0.0f;
+            pa[i] = p;
+            ds[i] = p * (dp[i] - row_delta[query]) * scale;
+          }
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 pf = acc_frag(pa, s2), df = acc_frag(ds, s2);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+              dvt[dt] = mfma(frag_cols(Ot, 32 * dt + r, 32 * mt, s2, h), pf, dvt[dt]);  // dV^T += dO^T P
+              dkt[dt] = mfma(frag_cols(Qt, 32 * dt + r, 32 * mt, s2, h), df, dkt[dt]);  // dK^T += Q^T dS
+            }
+          }
+        }
+      }
+    }
+  }
+  if (key < len) {
+    uint16_t* krow = dk + (start + key) * dk_ts + hkv * dk_hs;
+    uint16_t* vrow = dv + (start + key) * dv_ts + hkv * dv_hs;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 pk;
+        pk.x = pack_bf16(dkt[dt][4 * g + 0], dkt[dt][4 * g + 1]);
+        pk.y = pack_bf16(dkt[dt][4 * g + 2], dkt[dt][4 * g + 3]);
+        *reinterpret_cast<u32x2*>(krow + 32 * dt + 8 * g + 4 * h) = pk;
+        pk.x = pack_bf16(dvt[dt][4 * g + 0], dvt[dt][4 * g + 1]);
+        pk.y = pack_bf16(dvt[dt][4 * g + 2], dvt[dt][4 * g + 3]);
+        *reinterpret_cast<u32x2*>(vrow + 32 * dt + 8 * g + 4 * h) = pk;
+      }
+    }
+  }
+}
+
+static bool view_ok(const void* p, int64_t ts, int64_t hs) {
+  return p && (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ts % 8 == 0 && hs % 8 == 0 && ts > 0 && hs > 0;
+}
+
+constexpr size_t kFwdLds = 2 * kAImg * sizeof(uint16_t);
+constexpr size_t kDqLds = 3 * kAImg * sizeof(uint16_t);
+constexpr size_t kDkvLds = 4 * kAImg * sizeof(uint16_t) + 2 * kAL * sizeof(float);
+
+// The kernels use more than the 64 KB of LDS a launch gets by default; raised once per process and device.
+static int raise_lds_limits() {
+  static thread_local int done_for = -1;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return PRL_ELAUNCH;
+  if (done_for == dev) return PRL_OK;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_short_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)kFwdLds) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_short_bwd_dq),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDqLds) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_short_bwd_dkv),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDkvLds) != hipSuccess) {
+    set_error("attn_short: cannot raise the dynamic LDS limit: %s", hipGetErrorString(hipGetLastError()));
+    return PRL_ELAUNCH;
+  }
+  done_for = dev;
+  return PRL_OK;
+}
+
+}  // namespace prl
+
+using namespace prl;
+
+extern "C" int prl_attn_short_supported(int dtype, int64_t head_dim, int64_t max_len, int64_t q_heads,
+                                        int64_t kv_heads) {
+  return dtype == PRL_BF16 && head_dim == kAD && max_len >= 1 && max_len <= kAL && kv_heads >= 1 &&
+         q_heads >= kv_heads && q_heads % kv_heads == 0;
+}
+
+#define PRL_ATTN_COMMON_CHECKS(name)                                                                          \
+  PRL_REQUIRE(n_samples >= 0 && T >= 0 && q_heads >= 1 && kv_heads >= 1 && q_heads % kv_heads == 0,           \
+              name ": bad sizes (samples %d, T %lld, heads %d / %d)", n_samples, (long long)T, q_heads,      \
+              kv_heads);                                                                                      \
+  PRL_REQUIRE(scale > 0.0f, name ": the score scale must be positive");                                      \
+  if (n_samples == 0 || T == 0) return PRL_OK;                                                                \
+  PRL_REQUIRE(cu_seqlens, name ": the sample table must not be NULL");                                       \
+  PRL_REQUIRE((int64_t)n_samples * q_heads <= 0x7fffffffLL, name ": too many (sample, head) pairs")
+
+extern "C" int prl_attn_short_fwd(const void* q, const int64_t* q_strides, const void* k, const int64_t* k_strides,
+                                  const void* v, const int64_t* v_strides, void* out, const int64_t* out_strides,
+                                  float* lse2, const int32_t* cu_seqlens, int32_t n_samples, int64_t T,
+                                  int32_t q_heads, int32_t kv_heads, float scale, void* stream) {
+  clear_error();
+  PRL_ATTN_COMMON_CHECKS("attn_short_fwd");
+  PRL_REQUIRE(q_strides && k_strides && v_strides && out_strides && lse2, "attn_short_fwd: NULL argument");
+  PRL_REQUIRE(view_ok(q, q_strides[0], q_strides[1]) && view_ok(k, k_strides[0], k_strides[1]) &&
+                  view_ok(v, v_strides[0], v_strides[1]) && view_ok(out, out_strides[0], out_strides[1]),
+              "attn_short_fwd: tensors must be 16-byte aligned with token and head strides that are multiples of 8");
+  if (int rc = raise_lds_limits()) return rc;
+  const AttnView qv{static_cast<const uint16_t*>(q), q_strides[0], q_strides[1]};
+  const AttnView kv{static_cast<const uint16_t*>(k), k_strides[0], k_strides[1]};
+  const AttnView vv{static_cast<const uint16_t*>(v), v_strides[0], v_strides[1]};
+  hipLaunchKernelGGL(k_attn_short_fwd, dim3((unsigned)(n_samples * q_heads)), dim3(kAThreads), kFwdLds,
+                     (hipStream_t)stream, qv, kv, vv, static_cast<uint16_t*>(out), out_strides[0], out_strides[1],
+                     lse2, cu_seqlens, q_heads, q_heads / kv_heads, T, scale * kLog2e);
+  PRL_CHECK_LAUNCH("attn_short_fwd");
+  return PRL_OK;
+}
+
+extern "C" int prl_attn_short_bwd(const void* q, const int64_t* q_strides, const void* k, const int64_t* k_strides,
+                                  const void* v, const int64_t* v_strides, const void* out,
+                                  const int64_t* out_strides, const void* dout, const int64_t* dout_strides,
+                                  const float* lse2, float* delta, void* dq, const int64_t* dq_strides, void* dk,
+                                  const int64_t* dk_strides, void* dv, const int64_t* dv_strides,
+                                  const int32_t* cu_seqlens, int32_t n_samples, int64_t T, int32_t q_heads,
+                                  int32_t kv_heads, float scale, void* stream) {
+  clear_error();
+  PRL_ATTN_COMMON_CHECKS("attn_short_bwd");
+  PRL_REQUIRE(q_strides && k_strides && v_strides && out_strides && dout_strides && dq_strides && dk_strides &&
+                  dv_strides && lse2 && delta,
+              "attn_short_bwd: NULL argument");
+  PRL_REQUIRE(view_ok(q, q_strides[0], q_strides[1]) && view_ok(k, k_strides[0], k_strides[1]) &&
+                  view_ok(v, v_strides[0], v_strides[1]) && view_ok(out, out_strides[0], out_strides[1]) &&
+                  view_ok(dout, dout_strides[0], dout_strides[1]) && view_ok(dq, dq_strides[0], dq_strides[1]) &&
+                  view_ok(dk, dk_strides[0], dk_strides[1]) && view_ok(dv, dv_strides[0], dv_strides[1]),
+              "attn_short_bwd: tensors must be 16-byte aligned with token and head strides that are multiples of 8");
+  if (int rc = raise_lds_limits()) return rc;
+  const AttnView qv{static_cast<const uint16_t*>(q), q_strides[0], q_strides[1]};
+  const AttnView kv{static_cast<const uint16_t*>(k), k_strides[0], k_strides[1]};
+  const AttnView vv{static_cast<const uint16_t*>(v), v_strides[0], v_strides[1]};
+  const AttnView ov{static_cast<const uint16_t*>(out), out_strides[0], out_strides[1]};
+  const AttnView dov{static_cast<const uint16_t*>(dout), dout_strides[0], dout_strides[1]};
+  const int G = q_heads / kv_heads;
+  const float c = scale * kLog2e;
+  hipLaunchKernelGGL(k_attn_short_bwd_dq, dim3((unsigned)(n_samples * q_heads)), dim3(kAThreads), kDqLds,
+                     (hipStream_t)stream, qv, kv, vv, ov, dov, lse2, delta, static_cast<uint16_t*>(dq), dq_strides[0],
+                     dq_strides[1], cu_seqlens, q_heads, G, T, c, scale);
+  PRL_CHECK_LAUNCH("attn_short_bwd (dq)");
+  hipLaunchKernelGGL(k_attn_short_bwd_dkv, dim3((unsigned)(n_samples * kv_heads)), dim3(kAThreads), kDkvLds,
+                     (hipStream_t)stream, qv, kv, vv, dov, lse2, delta, static_cast<uint16_t*>(dk), dk_strides[0],
+                     dk_strides[1], static_cast<uint16_t*>(dv), dv_strides[0], dv_strides[1], cu_seqlens, kv_heads, G,
+                     T, c, scale);
+  PRL_CHECK_LAUNCH("attn_short_bwd (dk, dv)");
+  return PRL_OK;
+}

@@ -230,7 +230,7 @@ class Replica:
 
     @staticmethod
     def _key(mb: dict[str, Any], plan: Any, loss_config: LossConfig) -> tuple:
-        sig = None if plan is None else (plan.n, plan.lmax, plan.equal)
+        sig = None if plan is None else (plan.n, plan.lmax, plan.equal, plan.side_by_side, plan.cu is not None)
         return (tuple(mb["input_ids"].shape), float(mb["temperature"]), sig, loss_config.ratio_type,
                 bool(loss_config.ratio_length_norm), float(loss_config.clip_ratio))
 
@@ -238,13 +238,13 @@ class Replica:
         cap = _Captured()
         cap.inputs = {k: mb[k].clone() for k in _TENSOR_KEYS}
         cap.inputs["temperature"] = mb["temperature"]
-        if plan is not None and not plan.equal:
+        if plan is not None:  # the tables of the attention layout are inputs too
             import copy
 
             cap.plan = copy.copy(plan)
-            cap.plan.gather, cap.plan.scatter = plan.gather.clone(), plan.scatter.clone()
-        else:
-            cap.plan = plan
+            for name in ("gather", "scatter", "cu"):
+                if getattr(plan, name) is not None:
+                    setattr(cap.plan, name, getattr(plan, name).clone())
         cap.src = torch.zeros(len(self.state.params), dtype=torch.int64, device=self.device)
         cap.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(cap.graph):
@@ -278,9 +278,10 @@ class Replica:
             self._captured.move_to_end(key)
             for k in _TENSOR_KEYS:
                 cap.inputs[k].copy_(mb[k])
-            if cap.plan is not None and not cap.plan.equal:
-                cap.plan.gather.copy_(plan.gather)
-                cap.plan.scatter.copy_(plan.scatter)
+            if cap.plan is not None:
+                for name in ("gather", "scatter", "cu"):
+                    if getattr(plan, name) is not None:
+                        getattr(cap.plan, name).copy_(getattr(plan, name))
             cap.graph.replay()
             self.replays += 1
             return cap.loss.clone(), {k: cap.aux[k].clone() for k in _AUX_KEYS}
