@@ -226,11 +226,15 @@ int prl_scale_rows_if_not_one(void* x, int dtype, int64_t T, int64_t V, int64_t 
  */
 int prl_rmsnorm_supported(int dtype, int64_t H);
 size_t prl_rmsnorm_bwd_workspace_bytes(int dtype, int64_t rows, int64_t H);
+/* x_group > 0: the rows of x come in groups of x_group (x_row_stride inside a group, x_group_stride from group to
+ * group, in elements), e.g. the heads of a token inside the wider row of a stacked q/k/v projection; 0: plain rows. */
 int prl_rmsnorm_fwd(const void* x, int64_t x_row_stride, const void* w, void* y, int64_t y_row_stride, float* rstd,
-                    int dtype, int64_t rows, int64_t H, float eps, void* stream);
+                    int dtype, int64_t rows, int64_t H, float eps, int64_t x_group, int64_t x_group_stride,
+                    void* stream);
 int prl_rmsnorm_bwd(const void* x, int64_t x_row_stride, const void* w, const float* rstd, const void* gy,
                     int64_t gy_row_stride, void* gx, int64_t gx_row_stride, void* gw, int dtype, int64_t rows,
-                    int64_t H, void* workspace, size_t workspace_bytes, void* stream);
+                    int64_t H, void* workspace, size_t workspace_bytes, int64_t x_group, int64_t x_group_stride,
+                    void* stream);
 
 /*
  * Rotary position embedding of query and key in one launch:
@@ -261,6 +265,12 @@ int prl_rope(const void* q, void* q_out, const int64_t* q_strides, int64_t q_hea
 int prl_swiglu_fwd(const void* gate, const void* up, void* out, int dtype, int64_t n, void* stream);
 int prl_swiglu_bwd(const void* gate, const void* up, const void* gout, void* ggate, void* gup, int dtype, int64_t n,
                    void* stream);
+/* The same over `rows` rows of `cols` elements with row pitches (in elements): gate and up as column blocks of ONE
+ * wider matrix (the output of one product over the concatenated gate / up weights), and their gradients likewise. */
+int prl_swiglu_rows_fwd(const void* gate, const void* up, int64_t in_pitch, void* out, int64_t out_pitch, int dtype,
+                        int64_t rows, int64_t cols, void* stream);
+int prl_swiglu_rows_bwd(const void* gate, const void* up, int64_t in_pitch, const void* gout, int64_t gout_pitch,
+                        void* ggate, void* gup, int64_t grad_pitch, int dtype, int64_t rows, int64_t cols, void* stream);
 
 /*
  * Gradient accumulation over micro-batches into ONE flat fp32 buffer, one launch for all parameters:

@@ -88,6 +88,11 @@ SIGNATURES = {
          POINTER(c_int64), c_void_p, POINTER(c_int64), c_void_p, c_int32, c_int64, c_int32, c_int32, c_float,
          c_void_p],
     ),
+    "prl_swiglu_rows_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p]),
+    "prl_swiglu_rows_bwd": (
+        c_int,
+        [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p],
+    ),
     "prl_rope_supported": (c_int, [c_int, c_int64]),
     "prl_rope": (
         c_int,
@@ -98,12 +103,13 @@ SIGNATURES = {
     "prl_rmsnorm_bwd_workspace_bytes": (c_size_t, [c_int, c_int64, c_int64]),
     "prl_rmsnorm_fwd": (
         c_int,
-        [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int64, c_int64, c_float, c_void_p],
+        [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int64, c_int64, c_float, c_int64,
+         c_int64, c_void_p],
     ),
     "prl_rmsnorm_bwd": (
         c_int,
         [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int64,
-         c_int64, c_void_p, c_size_t, c_void_p],
+         c_int64, c_void_p, c_size_t, c_int64, c_int64, c_void_p],
     ),
     "prl_group_advantage": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "prl_stats_workspace_bytes": (c_size_t, [c_int]),

@@ -17,7 +17,7 @@
 // lane (S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS) and sums over the query heads of the group
 // in registers, so nothing is added across workgroups and nothing needs an atomic.
 // Operands that a product consumes along the token index (V in the forward, K, Q and dO in the backward)
-// are staged into LDS transposed, [d][token].
+// come out of the same natural [token][d] LDS images through the transposing read ds_read_b64_tr_b16.
 #include "prl_common.h"
 
 namespace prl {
@@ -64,32 +64,27 @@ __device__ __forceinline__ void stage_rows(uint16_t* img, const AttnView& x, int
     *reinterpret_cast<u32x4*>(img + tok * kAP + ch * 8) = v;
   }
 }
-// the same rows into a transposed [d][token] image
-__device__ __forceinline__ void stage_transposed(uint16_t* img, const AttnView& x, int64_t start, int len, int head) {
-  const int tok = threadIdx.x & (kAL - 1), half = threadIdx.x >> 7;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int ch = half * 8 + j;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (tok < len) v = *reinterpret_cast<const u32x4*>(x.p + (start + tok) * x.ts + head * x.hs + ch * 8);
-    uint16_t* col = img + (ch * 8) * kAP + tok;
-    col[0 * kAP] = (uint16_t)v.x, col[1 * kAP] = (uint16_t)(v.x >> 16);
-    col[2 * kAP] = (uint16_t)v.y, col[3 * kAP] = (uint16_t)(v.y >> 16);
-    col[4 * kAP] = (uint16_t)v.z, col[5 * kAP] = (uint16_t)(v.z >> 16);
-    col[6 * kAP] = (uint16_t)v.w, col[7 * kAP] = (uint16_t)(v.w >> 16);
-  }
-}
 // fragment of a natural image for a product that sums over d: row `row`, d = 16 kk + 8 h .. + 7
 __device__ __forceinline__ bf16x8 frag_rows(const uint16_t* img, int row, int kk, int h) {
   return as_frag(*reinterpret_cast<const u32x4*>(img + row * kAP + 16 * kk + 8 * h));
 }
-// fragment of a transposed image for a product whose other operand is an accumulator tile: row `row` (a d),
-// tokens tok0 + 16 s + 8 (j >> 2) + 4 h + (j & 3) in element j
-__device__ __forceinline__ bf16x8 frag_cols(const uint16_t* img, int row, int tok0, int s, int h) {
-  const uint16_t* p = img + row * kAP + tok0 + 16 * s + 4 * h;
-  const u32x2 lo = *reinterpret_cast<const u32x2*>(p), hi = *reinterpret_cast<const u32x2*>(p + 8);
-  u32x4 v = {lo.x, lo.y, hi.x, hi.y};
-  return as_frag(v);
+// Fragment of a natural [token][d] image for a product that sums over TOKENS and whose other operand is an
+// accumulator tile: lane (r, h) needs column d = d0 + r at tokens tok0 + 16 s + 8 (j >> 2) + 4 h + (j & 3) in
+// element j.  ds_read_b64_tr_b16 hands a 16-lane group a block of 4 rows x 16 columns transposed: lane 4q + p of
+// the group supplies the address of row q, columns 4p .. 4p+3, and lane i receives column i of the 4 rows.  The
+// four groups of a wave are (r < 16, h = 0), (r >= 16, h = 0), (r < 16, h = 1), (r >= 16, h = 1): columns
+// d0 + 16 (r >> 4) .. + 15, rows tok0 + 16 s + 4 h .. + 3, and 8 rows further for elements 4 .. 7.
+// Needs every lane of the wave active.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 frag_cols(const uint16_t* img, int d0, int tok0, int s, int lane) {
+  const int i = lane & 15, grp = lane >> 4;
+  const uint16_t* p = img + (tok0 + 16 * s + 4 * (grp >> 1) + (i >> 2)) * kAP + d0 + 16 * (grp & 1) + 4 * (i & 3);
+  typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + 8 * kAP));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  return __builtin_bit_cast(bf16x8, v);
 }
 // the same fragment of a row read from global memory (token `tok` of the sample, or zeros past its end)
 __device__ __forceinline__ bf16x8 frag_global(const AttnView& x, int64_t start, int len, int head, int tok, int kk,
@@ -116,7 +111,7 @@ __global__ __launch_bounds__(kAThreads) void k_attn_short_fwd(AttnView q, AttnVi
                                                               const int32_t* cu, int Hq, int G, int64_t T, float c) {
   extern __shared__ __align__(16) uint16_t lds[];
   uint16_t* Ks = lds;
-  uint16_t* Vt = lds + kAImg;
+  uint16_t* Vs = lds + kAImg;
   const int s = blockIdx.x / Hq, hq = blockIdx.x % Hq, hkv = hq / G;
   int64_t start;
   int len;
@@ -127,7 +122,7 @@ __global__ __launch_bounds__(kAThreads) void k_attn_short_fwd(AttnView q, AttnVi
 #pragma unroll
   for (int kk = 0; kk < 8; ++kk) qf[kk] = frag_global(q, start, len, hq, query, kk, h);
   stage_rows(Ks, k, start, len, hkv);
-  stage_transposed(Vt, v, start, len, hkv);
+  stage_rows(Vs, v, start, len, hkv);
   __syncthreads();
   int ntile = (len + 31) >> 5;
   if (ntile > w + 1) ntile = w + 1;  // causal: no key tile beyond the wave's own queries
@@ -175,7 +170,7 @@ __global__ __launch_bounds__(kAThreads) void k_attn_short_fwd(AttnView q, AttnVi
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8 pf = acc_frag(st[mt], s2);
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) ot[dt] = mfma(frag_cols(Vt, 32 * dt + r, 32 * mt, s2, h), pf, ot[dt]);
+        for (int dt = 0; dt < 4; ++dt) ot[dt] = mfma(frag_cols(Vs, 32 * dt, 32 * mt, s2, lane), pf, ot[dt]);
       }
     }
   }
@@ -205,7 +200,6 @@ __global__ __launch_bounds__(kAThreads) void k_attn_short_bwd_dq(AttnView q, Att
   extern __shared__ __align__(16) uint16_t lds[];
   uint16_t* Ks = lds;
   uint16_t* Vs = lds + kAImg;
-  uint16_t* Kt = lds + 2 * kAImg;
   const int s = blockIdx.x / Hq, hq = blockIdx.x % Hq, hkv = hq / G;
   int64_t start;
   int len;
@@ -234,7 +228,6 @@ __global__ __launch_bounds__(kAThreads) void k_attn_short_bwd_dq(AttnView q, Att
   }
   stage_rows(Ks, k, start, len, hkv);
   stage_rows(Vs, v, start, len, hkv);
-  stage_transposed(Kt, k, start, len, hkv);
   __syncthreads();
   int ntile = (len + 31) >> 5;
   if (ntile > w + 1) ntile = w + 1;
@@ -261,7 +254,7 @@ __global__ __launch_bounds__(kAThreads) void k_attn_short_bwd_dq(AttnView q, Att
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8 df = acc_frag(sa, s2);
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) dqt[dt] = mfma(frag_cols(Kt, 32 * dt + r, 32 * mt, s2, h), df, dqt[dt]);
+        for (int dt = 0; dt < 4; ++dt) dqt[dt] = mfma(frag_cols(Ks, 32 * dt, 32 * mt, s2, lane), df, dqt[dt]);
       }
     }
   }
@@ -289,10 +282,8 @@ __global__ __launch_bounds__(kAThreads) void k_attn_short_bwd_dkv(AttnView q, At
                                                                   float c, float scale) {
   extern __shared__ __align__(16) uint16_t lds[];
   uint16_t* Qs = lds;
-  uint16_t* Os = lds + kAImg;      // dO, natural
-  uint16_t* Qt = lds + 2 * kAImg;
-  uint16_t* Ot = lds + 3 * kAImg;  // dO, transposed
-  float* row_lse = reinterpret_cast<float*>(lds + 4 * kAImg);
+  uint16_t* Os = lds + kAImg;  // dO
+  float* row_lse = reinterpret_cast<float*>(lds + 2 * kAImg);
   float* row_delta = row_lse + kAL;
   const int s = blockIdx.x / Hkv, hkv = blockIdx.x % Hkv;
   int64_t start;
@@ -313,8 +304,6 @@ __global__ __launch_bounds__(kAThreads) void k_attn_short_bwd_dkv(AttnView q, At
     __syncthreads();  // the previous head's images are no longer read
     stage_rows(Qs, q, start, len, hq);
     stage_rows(Os, dout, start, len, hq);
-    stage_transposed(Qt, q, start, len, hq);
-    stage_transposed(Ot, dout, start, len, hq);
     if (threadIdx.x < kAL) {
       const bool in = (int)threadIdx.x < len;
       row_lse[threadIdx.x] = in ? lse2[(int64_t)hq * T + start + threadIdx.x] : 0.0f;
@@ -345,8 +334,8 @@ __global__ __launch_bounds__(kAThreads) void k_attn_short_bwd_dkv(AttnView q, At
             const bf16x8 pf = acc_frag(pa, s2), df = acc_frag(ds, s2);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-              dvt[dt] = mfma(frag_cols(Ot, 32 * dt + r, 32 * mt, s2, h), pf, dvt[dt]);  // dV^T += dO^T P
-              dkt[dt] = mfma(frag_cols(Qt, 32 * dt + r, 32 * mt, s2, h), df, dkt[dt]);  // dK^T += Q^T dS
+              dvt[dt] = mfma(frag_cols(Os, 32 * dt, 32 * mt, s2, lane), pf, dvt[dt]);  // dV^T += dO^T P
+              dkt[dt] = mfma(frag_cols(Qs, 32 * dt, 32 * mt, s2, lane), df, dkt[dt]);  // dK^T += Q^T dS
             }
           }
         }
@@ -377,8 +366,8 @@ static bool view_ok(const void* p, int64_t ts, int64_t hs) {
 }
 
 constexpr size_t kFwdLds = 2 * kAImg * sizeof(uint16_t);
-constexpr size_t kDqLds = 3 * kAImg * sizeof(uint16_t);
-constexpr size_t kDkvLds = 4 * kAImg * sizeof(uint16_t) + 2 * kAL * sizeof(float);
+constexpr size_t kDqLds = 2 * kAImg * sizeof(uint16_t);
+constexpr size_t kDkvLds = 2 * kAImg * sizeof(uint16_t) + 2 * kAL * sizeof(float);
 
 // The kernels use more than the 64 KB of LDS a launch gets by default; raised once per process and device.
 static int raise_lds_limits() {

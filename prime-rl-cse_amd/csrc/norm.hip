@@ -36,13 +36,24 @@ __device__ __forceinline__ void load_vec(const char* p, int64_t v, float* out) {
   decode16_raw<DT>(raw, out);
 }
 
+// Row `row` of x.  Plain rows have one pitch; with x_group > 0 the rows come in groups of x_group (pitch
+// x_stride inside a group, x_group_stride from group to group): the heads of a token inside a wider row, as
+// the query / key blocks of one stacked q/k/v projection are.
+__device__ __forceinline__ const char* x_row(const char* x, int64_t row, int64_t x_stride, int64_t x_group,
+                                             int64_t x_group_stride) {
+  if (x_group <= 0) return x + row * x_stride;
+  const int64_t grp = row / x_group;
+  return x + grp * x_group_stride + (row - grp * x_group) * x_stride;
+}
+
 // LPR lanes share a row (16 for short rows such as a 128-wide head, 64 otherwise); a lane owns the
 // 16-byte vectors li, li + LPR, ... of its row, NV of them at most.
 template <int DT, int LPR, int NV>
 __global__ __launch_bounds__(kNormThreads) void k_rmsnorm_fwd(const char* __restrict__ x, int64_t x_stride,
                                                               const char* __restrict__ w, char* __restrict__ y,
                                                               int64_t y_stride, float* __restrict__ rstd,
-                                                              int64_t rows, int H, float eps) {
+                                                              int64_t rows, int H, float eps, int64_t x_group,
+                                                              int64_t x_group_stride) {
   constexpr int VE = DT == PRL_F32 ? 4 : 8;
   constexpr int RPB = kNormThreads / LPR;  // rows per workgroup and step
   const int li = threadIdx.x % LPR, slot = threadIdx.x / LPR;
@@ -54,7 +65,7 @@ __global__ __launch_bounds__(kNormThreads) void k_rmsnorm_fwd(const char* __rest
     if (v < nvec) load_vec<DT>(w, v, wv[k]);
   }
   for (int64_t row = (int64_t)blockIdx.x * RPB + slot; row < rows; row += (int64_t)gridDim.x * RPB) {
-    const char* xp = x + row * x_stride;
+    const char* xp = x_row(x, row, x_stride, x_group, x_group_stride);
     float xv[NV][VE];
     float ss = 0.0f;
 #pragma unroll
@@ -91,7 +102,8 @@ __global__ __launch_bounds__(kNormThreads) void k_rmsnorm_bwd(const char* __rest
                                                               const float* __restrict__ rstd,
                                                               const char* __restrict__ gy, int64_t gy_stride,
                                                               char* __restrict__ gx, int64_t gx_stride,
-                                                              float* __restrict__ gw_part, int64_t rows, int H) {
+                                                              float* __restrict__ gw_part, int64_t rows, int H,
+                                                              int64_t x_group, int64_t x_group_stride) {
   constexpr int VE = DT == PRL_F32 ? 4 : 8;
   constexpr int RPB = kNormThreads / LPR;
   extern __shared__ float lds[];  // RPB * H floats: the row slots' column sums
@@ -107,7 +119,7 @@ __global__ __launch_bounds__(kNormThreads) void k_rmsnorm_bwd(const char* __rest
     for (int i = 0; i < VE; ++i) acc[k][i] = 0.0f;
   }
   for (int64_t row = (int64_t)blockIdx.x * RPB + slot; row < rows; row += (int64_t)gridDim.x * RPB) {
-    const char* xp = x + row * x_stride;
+    const char* xp = x_row(x, row, x_stride, x_group, x_group_stride);
     const char* gp = gy + row * gy_stride;
     const float rs = rstd[row];
     float xh[NV][VE], gw_[NV][VE];
@@ -237,10 +249,22 @@ static int norm_check(const char* who, int dtype, int64_t rows, int64_t H, const
   return PRL_OK;
 }
 
+static int norm_group_check(const char* who, int dtype, int64_t H, int64_t x_row_stride, int64_t x_group,
+                            int64_t x_group_stride) {
+  if (x_group <= 0) return PRL_OK;
+  const int es = dtype == PRL_F32 ? 4 : 2;
+  PRL_REQUIRE(x_group_stride >= (x_group - 1) * x_row_stride + H && ((x_group_stride * es) & 15) == 0,
+              "%s: the group stride must cover a group of rows and be 16-byte aligned", who);
+  return PRL_OK;
+}
+
 extern "C" int prl_rmsnorm_fwd(const void* x, int64_t x_row_stride, const void* w, void* y, int64_t y_row_stride,
-                               float* rstd, int dtype, int64_t rows, int64_t H, float eps, void* stream) {
+                               float* rstd, int dtype, int64_t rows, int64_t H, float eps, int64_t x_group,
+                               int64_t x_group_stride, void* stream) {
   clear_error();
   int rc = norm_check("rmsnorm_fwd", dtype, rows, H, x, w, y, x_row_stride, y_row_stride);
+  if (rc != PRL_OK) return rc;
+  rc = norm_group_check("rmsnorm_fwd", dtype, H, x_row_stride, x_group, x_group_stride);
   if (rc != PRL_OK) return rc;
   if (rows == 0) return PRL_OK;
   PRL_REQUIRE(x && w && y, "rmsnorm_fwd: x, w and y must not be NULL");
@@ -250,7 +274,7 @@ extern "C" int prl_rmsnorm_fwd(const void* x, int64_t x_row_stride, const void* 
   hipStream_t st = (hipStream_t)stream;
 #define PRL_FWD(DT, L, N, ...)                                                                                     \
   hipLaunchKernelGGL((k_rmsnorm_fwd<DT, L, N>), grid, block, 0, st, (const char*)x, x_row_stride * es, (const char*)w, \
-                     (char*)y, y_row_stride * es, rstd, rows, (int)H, eps)
+                     (char*)y, y_row_stride * es, rstd, rows, (int)H, eps, x_group, x_group_stride * es)
   PRL_NORM_DISPATCH(PRL_FWD, 0);
 #undef PRL_FWD
   PRL_CHECK_LAUNCH("rmsnorm_fwd");
@@ -259,9 +283,12 @@ extern "C" int prl_rmsnorm_fwd(const void* x, int64_t x_row_stride, const void* 
 
 extern "C" int prl_rmsnorm_bwd(const void* x, int64_t x_row_stride, const void* w, const float* rstd, const void* gy,
                                int64_t gy_row_stride, void* gx, int64_t gx_row_stride, void* gw, int dtype,
-                               int64_t rows, int64_t H, void* workspace, size_t workspace_bytes, void* stream) {
+                               int64_t rows, int64_t H, void* workspace, size_t workspace_bytes, int64_t x_group,
+                               int64_t x_group_stride, void* stream) {
   clear_error();
   int rc = norm_check("rmsnorm_bwd", dtype, rows, H, x, gy, gx, x_row_stride, gy_row_stride);
+  if (rc != PRL_OK) return rc;
+  rc = norm_group_check("rmsnorm_bwd", dtype, H, x_row_stride, x_group, x_group_stride);
   if (rc != PRL_OK) return rc;
   PRL_REQUIRE(gx_row_stride >= H && ((gx_row_stride * (dtype == PRL_F32 ? 4 : 2)) & 15) == 0,
               "rmsnorm_bwd: gx row stride must be >= H and 16-byte aligned");
@@ -279,7 +306,8 @@ extern "C" int prl_rmsnorm_bwd(const void* x, int64_t x_row_stride, const void* 
   const size_t lds = (size_t)(kNormThreads / lpr) * H * sizeof(float);
 #define PRL_BWD(DT, L, N, ...)                                                                                      \
   hipLaunchKernelGGL((k_rmsnorm_bwd<DT, L, N>), grid, block, lds, st, (const char*)x, x_row_stride * es, (const char*)w, \
-                     rstd, (const char*)gy, gy_row_stride * es, (char*)gx, gx_row_stride * es, part, rows, (int)H)
+                     rstd, (const char*)gy, gy_row_stride * es, (char*)gx, gx_row_stride * es, part, rows, (int)H, \
+                     x_group, x_group_stride * es)
   PRL_NORM_DISPATCH(PRL_BWD, 0);
 #undef PRL_BWD
   PRL_CHECK_LAUNCH("rmsnorm_bwd");
@@ -446,6 +474,50 @@ __global__ __launch_bounds__(256) void k_swiglu_bwd(const char* __restrict__ gat
   }
 }
 
+// The same two kernels over ROWS with a pitch: gate and up are column blocks of one wider matrix (the output
+// of one product over the concatenated gate / up weights), and so are their gradients.
+template <int DT>
+__global__ __launch_bounds__(256) void k_swiglu_rows_fwd(const char* __restrict__ gate, const char* __restrict__ up,
+                                                         int64_t in_pitch, char* __restrict__ out, int64_t out_pitch,
+                                                         int64_t rows, int64_t row_vecs) {
+  constexpr int VE = DT == PRL_F32 ? 4 : 8;
+  const int64_t nvec = rows * row_vecs;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
+    const int64_t row = v / row_vecs, cv = v - row * row_vecs;
+    float g[VE], u[VE], o[VE];
+    load_vec<DT>(gate + row * in_pitch, cv, g);
+    load_vec<DT>(up + row * in_pitch, cv, u);
+#pragma unroll
+    for (int i = 0; i < VE; ++i) o[i] = round_to(g[i] * sigmoidf_(g[i]), DT) * u[i];
+    store_unit<DT, VE>(out + row * out_pitch, cv, o);
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_swiglu_rows_bwd(const char* __restrict__ gate, const char* __restrict__ up,
+                                                         int64_t in_pitch, const char* __restrict__ gout,
+                                                         int64_t gout_pitch, char* __restrict__ ggate,
+                                                         char* __restrict__ gup, int64_t grad_pitch, int64_t rows,
+                                                         int64_t row_vecs) {
+  constexpr int VE = DT == PRL_F32 ? 4 : 8;
+  const int64_t nvec = rows * row_vecs;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
+    const int64_t row = v / row_vecs, cv = v - row * row_vecs;
+    float g[VE], u[VE], d[VE], dg[VE], du[VE];
+    load_vec<DT>(gate + row * in_pitch, cv, g);
+    load_vec<DT>(up + row * in_pitch, cv, u);
+    load_vec<DT>(gout + row * gout_pitch, cv, d);
+#pragma unroll
+    for (int i = 0; i < VE; ++i) {
+      const float s = sigmoidf_(g[i]);
+      du[i] = d[i] * round_to(g[i] * s, DT);
+      dg[i] = round_to(d[i] * u[i], DT) * (s * (1.0f + g[i] * (1.0f - s)));
+    }
+    store_unit<DT, VE>(ggate + row * grad_pitch, cv, dg);
+    store_unit<DT, VE>(gup + row * grad_pitch, cv, du);
+  }
+}
+
 }  // namespace prl
 
 static int swiglu_check(const char* who, int dtype, int64_t n, const void* a, const void* b, const void* c) {
@@ -495,5 +567,65 @@ extern "C" int prl_swiglu_bwd(const void* gate, const void* up, const void* gout
     hipLaunchKernelGGL((prl::k_swiglu_bwd<PRL_F32>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)gate,
                        (const char*)up, (const char*)gout, (char*)ggate, (char*)gup, nvec);
   PRL_CHECK_LAUNCH("swiglu_bwd");
+  return PRL_OK;
+}
+
+static int swiglu_rows_check(const char* who, int dtype, int64_t rows, int64_t cols, int n_pitch,
+                             const int64_t* pitches, int n_ptr, const void* const* ptrs) {
+  if (dtype != PRL_F32 && dtype != PRL_BF16) {
+    prl::set_error("%s: unsupported dtype code %d", who, dtype);
+    return PRL_EDTYPE;
+  }
+  const int ve = dtype == PRL_F32 ? 4 : 8;
+  PRL_REQUIRE(rows >= 0 && cols >= 0 && cols % ve == 0, "%s: the row length must be a multiple of %d", who, ve);
+  for (int i = 0; i < n_pitch; ++i)
+    PRL_REQUIRE(pitches[i] >= cols && pitches[i] % ve == 0, "%s: a row pitch is shorter than a row or not a multiple of %d",
+                who, ve);
+  for (int i = 0; i < n_ptr; ++i)
+    PRL_REQUIRE(rows * cols == 0 || (ptrs[i] && (reinterpret_cast<uintptr_t>(ptrs[i]) & 15) == 0),
+                "%s: tensors must be 16-byte aligned and not NULL", who);
+  return PRL_OK;
+}
+
+extern "C" int prl_swiglu_rows_fwd(const void* gate, const void* up, int64_t in_pitch, void* out, int64_t out_pitch,
+                                   int dtype, int64_t rows, int64_t cols, void* stream) {
+  clear_error();
+  const int64_t pitches[2] = {in_pitch, out_pitch};
+  const void* ptrs[3] = {gate, up, out};
+  int rc = swiglu_rows_check("swiglu_rows_fwd", dtype, rows, cols, 2, pitches, 3, ptrs);
+  if (rc != PRL_OK || rows * cols == 0) return rc;
+  const int es = dtype == PRL_F32 ? 4 : 2;
+  const int64_t row_vecs = cols * es / 16, want = (rows * row_vecs + 255) / 256;
+  const dim3 grid((unsigned)(want < 8192 ? want : 8192));
+  if (dtype == PRL_BF16)
+    hipLaunchKernelGGL((prl::k_swiglu_rows_fwd<PRL_BF16>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)gate,
+                       (const char*)up, in_pitch * es, (char*)out, out_pitch * es, rows, row_vecs);
+  else
+    hipLaunchKernelGGL((prl::k_swiglu_rows_fwd<PRL_F32>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)gate,
+                       (const char*)up, in_pitch * es, (char*)out, out_pitch * es, rows, row_vecs);
+  PRL_CHECK_LAUNCH("swiglu_rows_fwd");
+  return PRL_OK;
+}
+
+extern "C" int prl_swiglu_rows_bwd(const void* gate, const void* up, int64_t in_pitch, const void* gout,
+                                   int64_t gout_pitch, void* ggate, void* gup, int64_t grad_pitch, int dtype,
+                                   int64_t rows, int64_t cols, void* stream) {
+  clear_error();
+  const int64_t pitches[3] = {in_pitch, gout_pitch, grad_pitch};
+  const void* ptrs[5] = {gate, up, gout, ggate, gup};
+  int rc = swiglu_rows_check("swiglu_rows_bwd", dtype, rows, cols, 3, pitches, 5, ptrs);
+  if (rc != PRL_OK || rows * cols == 0) return rc;
+  const int es = dtype == PRL_F32 ? 4 : 2;
+  const int64_t row_vecs = cols * es / 16, want = (rows * row_vecs + 255) / 256;
+  const dim3 grid((unsigned)(want < 8192 ? want : 8192));
+  if (dtype == PRL_BF16)
+    hipLaunchKernelGGL((prl::k_swiglu_rows_bwd<PRL_BF16>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)gate,
+                       (const char*)up, in_pitch * es, (const char*)gout, gout_pitch * es, (char*)ggate, (char*)gup,
+                       grad_pitch * es, rows, row_vecs);
+  else
+    hipLaunchKernelGGL((prl::k_swiglu_rows_bwd<PRL_F32>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)gate,
+                       (const char*)up, in_pitch * es, (const char*)gout, gout_pitch * es, (char*)ggate, (char*)gup,
+                       grad_pitch * es, rows, row_vecs);
+  PRL_CHECK_LAUNCH("swiglu_rows_bwd");
   return PRL_OK;
 }

@@ -24,51 +24,74 @@ from torch import Tensor, nn
 from . import _capi as C
 
 
+def _row_layout(x: Tensor):
+    """How the kernels walk the rows of x (last dimension contiguous): (rows, row stride, group, group stride),
+    group = 0 for evenly pitched rows, or None when x is neither that nor groups of evenly pitched rows."""
+    h = x.shape[-1]
+    rows = x.numel() // h
+    try:
+        x2 = x.view(rows, h)
+        return rows, (x2.stride(0) if rows > 1 else h), 0, 0
+    except RuntimeError:
+        pass
+    if x.ndim >= 3:
+        try:
+            x3 = x.view(-1, x.shape[-2], h)  # e.g. [token][head][d] inside a wider token row
+        except RuntimeError:
+            return None
+        es = x.element_size()
+        if (x3.stride(0) * es) % 16 == 0 and (x3.stride(1) * es) % 16 == 0:
+            return rows, x3.stride(1), x3.shape[1], x3.stride(0)
+    return None
+
+
 class _RMSNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, weight: Tensor, eps: float):
         dev = C.require_device(x, weight)
         lib = C.load()
         h = x.shape[-1]
-        x2 = x.reshape(-1, h)  # a view whenever the leading dimensions are laid out evenly; else one copy
-        if x2.stride(-1) != 1:
-            x2 = x2.contiguous()
-        rows = x2.shape[0]
+        layout = _row_layout(x) if x.stride(-1) == 1 else None
+        if layout is None:
+            x = x.contiguous()
+            layout = _row_layout(x)
+        rows, stride, group, group_stride = layout
         w = weight.contiguous()
         y = torch.empty((rows, h), dtype=x.dtype, device=dev)
         rstd = torch.empty(rows, dtype=torch.float32, device=dev)
         with C.on_device(dev), C.timed("prl_rmsnorm_fwd", dev):
             C.check(
-                lib.prl_rmsnorm_fwd(C.ptr(x2), x2.stride(0) if rows > 1 else h, C.ptr(w), C.ptr(y), h, C.ptr(rstd),
-                                    C.dtype_code(x), rows, h, eps, C.stream_ptr(dev)),
+                lib.prl_rmsnorm_fwd(C.ptr(x), stride, C.ptr(w), C.ptr(y), h, C.ptr(rstd), C.dtype_code(x), rows, h, eps,
+                                    group, group_stride, C.stream_ptr(dev)),
                 "prl_rmsnorm_fwd",
             )
-        ctx.save_for_backward(x2, w, rstd)
-        ctx.shape = x.shape
+        ctx.save_for_backward(x, w, rstd)
+        ctx.layout = layout
         return y.view(x.shape)
 
     @staticmethod
     def backward(ctx, gy: Tensor):
-        x2, w, rstd = ctx.saved_tensors
-        dev = x2.device
+        x, w, rstd = ctx.saved_tensors
+        dev = x.device
         lib = C.load()
-        rows, h = x2.shape
+        rows, stride, group, group_stride = ctx.layout
+        h = x.shape[-1]
         g2 = gy.reshape(rows, h)
         if g2.stride(-1) != 1 or (rows > 1 and (g2.stride(0) * g2.element_size()) % 16) or g2.data_ptr() % 16:
             g2 = g2.contiguous()
-        gx = torch.empty((rows, h), dtype=x2.dtype, device=dev)
+        gx = torch.empty((rows, h), dtype=x.dtype, device=dev)
         gw = torch.empty(h, dtype=w.dtype, device=dev)
-        code = C.dtype_code(x2)
+        code = C.dtype_code(x)
         ws_bytes = lib.prl_rmsnorm_bwd_workspace_bytes(code, rows, h)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         with C.on_device(dev), C.timed("prl_rmsnorm_bwd", dev):
             C.check(
-                lib.prl_rmsnorm_bwd(C.ptr(x2), x2.stride(0) if rows > 1 else h, C.ptr(w), C.ptr(rstd), C.ptr(g2),
+                lib.prl_rmsnorm_bwd(C.ptr(x), stride, C.ptr(w), C.ptr(rstd), C.ptr(g2),
                                     g2.stride(0) if rows > 1 else h, C.ptr(gx), h, C.ptr(gw), code, rows, h,
-                                    C.ptr(ws), ws_bytes, C.stream_ptr(dev)),
+                                    C.ptr(ws), ws_bytes, group, group_stride, C.stream_ptr(dev)),
                 "prl_rmsnorm_bwd",
             )
-        return gx.view(ctx.shape), gw, None
+        return gx.view(x.shape), gw, None
 
 
 _NORM_SHAPES: dict[tuple[torch.dtype, int], bool] = {}
@@ -207,7 +230,110 @@ def swiglu(gate: Tensor, up: Tensor) -> Tensor:
     return _SwiGLU.apply(gate, up)
 
 
+# --------------------------------------------------------------------------- one product for adjacent weights
+
+
+def adjacent_rows(*weights: Tensor) -> Tensor | None:
+    """One [sum of rows, K] view over 2-D weights that lie back to back in ONE storage (as the parameters of a
+    block do in `replica.FlatState`'s flat buffer), or None.  A product over it replaces one product per
+    weight: at 2048 tokens the blocks' GEMMs are too small to fill 256 compute units one by one (q + k + v
+    separately 44 us, together 23 us; their weight gradients 61 -> 29 us)."""
+    w0 = weights[0]
+    if w0.ndim != 2 or not w0.is_cuda:
+        return None
+    base = w0.untyped_storage().data_ptr()
+    ptr, rows = w0.data_ptr(), 0
+    for w in weights:
+        if w.ndim != 2 or w.dtype != w0.dtype or w.shape[1] != w0.shape[1] or not w.is_contiguous() \
+                or w.untyped_storage().data_ptr() != base or w.data_ptr() != ptr or hasattr(w, "to_local"):
+            return None
+        ptr += w.numel() * w.element_size()
+        rows += w.shape[0]
+    return torch.as_strided(w0.detach(), (rows, w0.shape[1]), (w0.shape[1], 1))
+
+
+def _rows2d(x: Tensor) -> Tensor:
+    x2 = x.reshape(-1, x.shape[-1])
+    return x2 if x2.is_contiguous() else x2.contiguous()
+
+
+class _LinearSplit(torch.autograd.Function):
+    """y = x W^T for W = the adjacent weights stacked, returned split per weight (views of one matrix); the
+    backward joins the pieces' gradients and runs ONE product each for dx and for the stacked dW."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, stacked: Tensor, *weights: Tensor):
+        x2 = _rows2d(x)
+        y = x2 @ stacked.t()
+        ctx.save_for_backward(x2, stacked)
+        ctx.sizes = [w.shape[0] for w in weights]
+        ctx.lead = x.shape[:-1]
+        return tuple(p.view(*ctx.lead, p.shape[-1]) for p in y.split(ctx.sizes, dim=1))
+
+    @staticmethod
+    def backward(ctx, *grads: Tensor):
+        x2, stacked = ctx.saved_tensors
+        rows = x2.shape[0]
+        parts = [torch.zeros((rows, n), dtype=x2.dtype, device=x2.device) if g is None else g.reshape(rows, n)
+                 for g, n in zip(grads, ctx.sizes)]
+        gy = torch.cat(parts, dim=1)
+        dx = (gy @ stacked).view(*ctx.lead, x2.shape[1]) if ctx.needs_input_grad[0] else None
+        dw = (gy.t() @ x2).split(ctx.sizes, dim=0)
+        return (dx, None) + tuple(dw)
+
+
+class _GateUpSwiGLU(torch.autograd.Function):
+    """silu(x Wg^T) * (x Wu^T) with ONE product over the stacked [Wg; Wu] and the activation kernels working on
+    column blocks of its output; the backward writes both gradients into one matrix and runs one product each
+    for dx and for the stacked dW."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, stacked: Tensor, wg: Tensor, wu: Tensor):
+        dev = x.device
+        x2 = _rows2d(x)
+        gu = x2 @ stacked.t()
+        rows, n = x2.shape[0], wg.shape[0]
+        out = torch.empty((rows, n), dtype=x.dtype, device=dev)
+        es = x.element_size()
+        with C.on_device(dev), C.timed("prl_swiglu_rows_fwd", dev):
+            C.check(C.load().prl_swiglu_rows_fwd(gu.data_ptr(), gu.data_ptr() + n * es, 2 * n, C.ptr(out), n,
+                                                 C.dtype_code(x), rows, n, C.stream_ptr(dev)), "prl_swiglu_rows_fwd")
+        ctx.save_for_backward(x2, gu, stacked)
+        ctx.lead, ctx.n = x.shape[:-1], n
+        return out.view(*ctx.lead, n)
+
+    @staticmethod
+    def backward(ctx, gout: Tensor):
+        x2, gu, stacked = ctx.saved_tensors
+        dev = x2.device
+        rows, n = x2.shape[0], ctx.n
+        g2 = gout.reshape(rows, n)
+        if g2.stride(1) != 1 or g2.stride(0) % 8 or g2.data_ptr() % 16:
+            g2 = g2.contiguous()
+        ggu = torch.empty_like(gu)
+        es = gu.element_size()
+        with C.on_device(dev), C.timed("prl_swiglu_rows_bwd", dev):
+            C.check(C.load().prl_swiglu_rows_bwd(gu.data_ptr(), gu.data_ptr() + n * es, 2 * n, C.ptr(g2), g2.stride(0),
+                                                 ggu.data_ptr(), ggu.data_ptr() + n * es, 2 * n, C.dtype_code(gu), rows,
+                                                 n, C.stream_ptr(dev)), "prl_swiglu_rows_bwd")
+        dx = (ggu @ stacked).view(*ctx.lead, x2.shape[1]) if ctx.needs_input_grad[0] else None
+        dw = ggu.t() @ x2
+        return dx, None, dw[:n], dw[n:]
+
+
+def _stackable(x: Tensor, *linears: nn.Module) -> Tensor | None:
+    if any(getattr(m, "bias", None) is not None for m in linears) or not x.is_cuda:
+        return None
+    if x.dtype not in (torch.bfloat16, torch.float32) or x.dtype != linears[0].weight.dtype:
+        return None
+    return adjacent_rows(*(m.weight for m in linears))
+
+
 def _fused_mlp_forward(self: nn.Module, x: Tensor) -> Tensor:
+    wg, wu = self.gate_proj.weight, self.up_proj.weight
+    stacked = _stackable(x, self.gate_proj, self.up_proj) if wg.shape == wu.shape else None
+    if stacked is not None and wg.shape[0] % (16 // x.element_size()) == 0:
+        return self.down_proj(_GateUpSwiGLU.apply(x, stacked, wg, wu))
     gate, up = self.gate_proj(x), self.up_proj(x)
     if swiglu_supported(gate, up):
         return self.down_proj(swiglu(gate, up))
@@ -227,10 +353,50 @@ def _fused_rmsnorm_forward(self: nn.Module, hidden_states: Tensor) -> Tensor:
     return self._prl_torch_forward(hidden_states)
 
 
+class _QKVShare:
+    """What the three projections of one attention module share: the query projection, called first, runs the
+    stacked product and leaves the key and value pieces for the two calls that follow on the same input."""
+
+    def __init__(self, attn: nn.Module):
+        self.attn = attn
+        self.x: Tensor | None = None
+        self.k: Tensor | None = None
+        self.v: Tensor | None = None
+
+
+def _q_forward(self: nn.Module, x: Tensor) -> Tensor:
+    share: _QKVShare = self._prl_qkv
+    attn = share.attn
+    stacked = _stackable(x, attn.q_proj, attn.k_proj, attn.v_proj)
+    if stacked is None:
+        share.x = None
+        return self._prl_torch_forward(x)
+    q, share.k, share.v = _LinearSplit.apply(x, stacked, attn.q_proj.weight, attn.k_proj.weight, attn.v_proj.weight)
+    share.x = x
+    return q
+
+
+def _k_forward(self: nn.Module, x: Tensor) -> Tensor:
+    share: _QKVShare = self._prl_qkv
+    if share.x is x and share.k is not None:
+        k, share.k = share.k, None
+        return k
+    return self._prl_torch_forward(x)
+
+
+def _v_forward(self: nn.Module, x: Tensor) -> Tensor:
+    share: _QKVShare = self._prl_qkv
+    if share.x is x and share.v is not None:
+        v, share.v, share.x = share.v, None, None
+        return v
+    share.x = None
+    return self._prl_torch_forward(x)
+
+
 def fuse_model(model: nn.Module) -> dict[str, int]:
     """Rebind the forward of every RMSNorm module of an HF causal LM to the HIP kernel.  Returns what was
     rebound, by kind.  Call it before FSDP wrapping or after; parameters are left as they are."""
-    done = {"rmsnorm": 0, "rope": 0, "swiglu": 0}
+    done = {"rmsnorm": 0, "rope": 0, "swiglu": 0, "qkv": 0}
     import sys
 
     home = sys.modules.get(type(model).__module__)  # e.g. transformers.models.qwen3.modeling_qwen3
@@ -254,6 +420,15 @@ def fuse_model(model: nn.Module) -> dict[str, int]:
             module._prl_torch_forward = module.forward
             module.forward = types.MethodType(_fused_mlp_forward, module)
             done["swiglu"] += 1
+        projections = [getattr(module, a, None) for a in ("q_proj", "k_proj", "v_proj")]
+        if name.endswith("Attention") and all(isinstance(m, nn.Linear) and m.bias is None for m in projections) \
+                and not hasattr(projections[0], "_prl_torch_forward"):
+            share = _QKVShare(module)
+            for m, fn in zip(projections, (_q_forward, _k_forward, _v_forward)):
+                m._prl_torch_forward = m.forward
+                m._prl_qkv = share
+                m.forward = types.MethodType(fn, m)
+            done["qkv"] += 1
     return done
 
 
@@ -267,6 +442,8 @@ def unfuse_model(model: nn.Module) -> None:
         if hasattr(module, "_prl_torch_forward"):
             module.forward = module._prl_torch_forward
             del module._prl_torch_forward
+            if hasattr(module, "_prl_qkv"):
+                del module._prl_qkv
 
 
 def describe(model: nn.Module) -> Any:

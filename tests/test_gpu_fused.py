@@ -244,7 +244,7 @@ def test_fuse_model_rebinds_the_gated_mlps():
     cfg = T.model_config("Qwen/Qwen3-0.6B", num_layers=3)
     model = T.get_model(cfg, DEV, torch.bfloat16, seed=3)
     done = fused.fuse_model(model)
-    assert done == {"rmsnorm": 13, "rope": 1, "swiglu": 3}
+    assert done == {"rmsnorm": 13, "rope": 1, "swiglu": 3, "qkv": 3}
     ids = torch.randint(0, 1000, (1, 64), device=DEV)
     pos = torch.arange(64, device=DEV)[None]
     timer = prl._capi.KernelTimer()
@@ -257,3 +257,72 @@ def test_fuse_model_rebinds_the_gated_mlps():
     s = timer.summary()
     assert s["prl_swiglu_fwd"]["launches"] == 3 and s["prl_swiglu_bwd"]["launches"] == 3
     fused.unfuse_model(model)
+
+
+def test_rmsnorm_over_the_heads_of_a_wider_row():
+    """The query block of a stacked q/k/v projection: [token][head][128] inside rows of 4096."""
+    gen = torch.Generator().manual_seed(4)
+    for dtype in (torch.bfloat16, torch.float32):
+        wide = torch.randn(1, 70, 4096, generator=gen).to(dtype).to(DEV)
+        w = (1.0 + 0.1 * torch.randn(128, generator=gen)).to(dtype).to(DEV)
+        x = wide[..., 1024:3072].view(1, 70, 16, 128)
+        assert not x.is_contiguous() and fused.rms_norm_supported(x, w)
+        x1 = x.detach().clone().requires_grad_(True)  # contiguous copy: the plain-rows path
+        w1 = w.clone().requires_grad_(True)
+        gy = torch.randn(x.shape, generator=gen).to(dtype).to(DEV)
+        y1 = fused.rms_norm(x1, w1, 1e-6)
+        y1.backward(gy)
+        wide2 = wide.clone().requires_grad_(True)
+        w2 = w.clone().requires_grad_(True)
+        y2 = fused.rms_norm(wide2[..., 1024:3072].view(1, 70, 16, 128), w2, 1e-6)
+        y2.backward(gy)
+        assert torch.equal(y2, y1) and torch.equal(w2.grad, w1.grad)
+        assert torch.equal(wide2.grad[..., 1024:3072].reshape(x.shape), x1.grad)
+        assert not wide2.grad[..., :1024].any() and not wide2.grad[..., 3072:].any()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_stacked_products_over_adjacent_weights_match_the_separate_ones(dtype):
+    """With the parameters laid back to back (replica.FlatState) the q/k/v and gate/up products run stacked;
+    logits and every gradient agree with the same model run product by product."""
+    import copy
+
+    from prime_rl_cse_amd import attention
+    from prime_rl_cse_amd import trainer as T
+    from prime_rl_cse_amd.replica import FlatState
+
+    cfg = T.model_config("Qwen/Qwen3-0.6B", num_layers=2, vocab_size=4096)
+    plain = T.get_model(cfg, DEV, dtype, seed=5)
+    stacked = copy.deepcopy(plain)
+    fused.fuse_model(stacked)
+    state = FlatState(stacked, compute_dtype=dtype)
+    layer = stacked.model.layers[0]
+    assert fused.adjacent_rows(layer.self_attn.q_proj.weight, layer.self_attn.k_proj.weight,
+                               layer.self_attn.v_proj.weight).shape == (4096, 1024)
+    assert fused.adjacent_rows(layer.mlp.gate_proj.weight, layer.mlp.up_proj.weight).shape == (6144, 1024)
+    assert fused.adjacent_rows(plain.model.layers[0].mlp.gate_proj.weight,
+                               plain.model.layers[0].mlp.up_proj.weight) is None  # separate allocations
+    lengths = [40, 24, 64]
+    t = sum(lengths)
+    gen = torch.Generator().manual_seed(6)
+    ids = torch.randint(0, 4096, (1, t), generator=gen).to(DEV)
+    pos = torch.cat([torch.arange(n) for n in lengths])[None]
+    plan = attention.plan_from_position_ids(pos, DEV)
+    calls = []
+    real = fused._LinearSplit.apply
+    try:
+        fused._LinearSplit.apply = staticmethod(lambda *a: (calls.append(1), real(*a))[1])
+        got = T.forward(stacked, ids, pos.to(DEV), plan)
+    finally:
+        fused._LinearSplit.apply = real
+    assert len(calls) == 2  # one stacked q/k/v product per layer
+    want = T.forward(plain, ids, pos.to(DEV), plan)
+    got.float().square().mean().backward()
+    want.float().square().mean().backward()
+    tol = 1e-4 if dtype == torch.float32 else 3e-2
+    scale = want.float().abs().max().item()
+    assert (got.float() - want.float()).abs().max().item() <= tol * scale
+    for (name, a), b in zip(plain.named_parameters(), state.params):
+        assert b.grad is not None and b.grad.shape == a.grad.shape, name
+        assert (b.grad.float() - a.grad.float()).norm().item() <= tol * a.grad.float().norm().item() + 1e-9, name
+    fused.unfuse_model(stacked)
