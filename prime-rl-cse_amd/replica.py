@@ -297,24 +297,38 @@ class Replica:
 
     def train_step(self, micro_batches: list[MicroBatch], loss_config: LossConfig, max_norm: float | None = 1.0,
                    scheduler: Any = None, samples: int | None = None,
-                   recomputed_errors: list[Tensor] | None = None) -> Any:
+                   recomputed_errors: list[Tensor] | None = None, join_tokens: int | None = None) -> Any:
         """One optimizer step over this rank's micro-batches (src/prime_rl/trainer/rl/train.py:259-364);
-        same results and the same `StepResult` as `trainer.train_step`."""
-        from .trainer import StepResult, attention_plan, local_loss_scale
+        same results and the same `StepResult` as `trainer.train_step`, micro-batches joined the same way."""
+        from .trainer import MERGE_MAX_TOKENS
+
+        join_tokens = MERGE_MAX_TOKENS if join_tokens is None else join_tokens
+        from .trainer import (StepResult, attention_plan, join_micro_batches, join_per_row, local_loss_scale,
+                              restore_row_starts)
 
         t0 = time.perf_counter()
         inv_scale = 1.0 / max(float(local_loss_scale(micro_batches, loss_config)), 1.0)
         self._scale.fill_(inv_scale)
         tensors = Tensors()
         tokens = 0
-        for step_idx, host_mb in enumerate(micro_batches):
+        rows = join_micro_batches(micro_batches, join_tokens) if loss_config.ratio_type == "token" and join_tokens > 0 \
+            else None
+        units = [r.micro_batch for r in rows] if rows is not None else micro_batches
+        if rows is not None and recomputed_errors is not None:
+            recomputed_errors = join_per_row(recomputed_errors, rows)
+        vocab = int(self.model.config.vocab_size)
+        for step_idx, host_mb in enumerate(units):
             mb = to_device(host_mb, self.device)
             loss, aux = self.micro_batch(mb, attention_plan(host_mb, self.device), loss_config)
-            mask = mb["loss_mask"]
+            if rows is not None:
+                losses = restore_row_starts(rows[step_idx], mb, aux, loss_config, vocab, inv_scale)
+                mask = rows[step_idx].loss_mask.to(self.device, non_blocking=True)
+            else:
+                losses, mask = (loss * inv_scale).reshape(1), mb["loss_mask"]
             tensors.add("probs", aux["logprobs"], mask, exp=True)
             tensors.add("old_probs", mb["logprobs"], mask, exp=True)
             tensors.add("entropy", aux["entropy"], mask)
-            tensors.add("loss", (loss * inv_scale).reshape(1))
+            tensors.add("loss", losses)
             if recomputed_errors is not None:
                 tensors.add("recomputed_logprob_error", recomputed_errors[step_idx], mask)
             if loss_config.ratio_type == "token":
@@ -329,7 +343,7 @@ class Replica:
         if samples is None:
             samples = len(micro_batches)
         return StepResult(loss=stats.get("loss/mean", float("nan")), grad_norm=float(grad_norm), stats=stats,
-                          seconds=seconds, tokens=tokens, samples=samples)
+                          seconds=seconds, tokens=tokens, samples=samples, passes=len(units))
 
 
 def eligible(model: nn.Module, optim_type: str, activation_checkpointing: bool = False) -> str | None:

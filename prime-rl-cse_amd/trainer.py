@@ -158,6 +158,7 @@ class StepResult:
     tokens: int
     samples: int
     timings: dict[str, float] = field(default_factory=dict)
+    passes: int = 0  # forward / backward passes the step took (fewer than micro-batches when rows were joined)
 
 
 def local_loss_scale(micro_batches: list[MicroBatch], loss_config: LossConfig) -> int:
@@ -170,20 +171,124 @@ def local_loss_scale(micro_batches: list[MicroBatch], loss_config: LossConfig) -
     return int(micro_batches[0]["input_ids"].shape[0] * len(micro_batches))
 
 
+MERGE_MAX_TOKENS = 16384  # longest joined row (the one-launch loss kernel's limit, 5 GB of bf16 logits at V = 152 K)
+
+
+@dataclass
+class JoinedRows:
+    """Several packed rows of a step joined end to end into one, for ONE forward / backward over all of them."""
+
+    micro_batch: MicroBatch  # the joined row; the first token of every row but the first is masked out (see below)
+    starts: list[int]  # first token of every original row
+    lengths: list[int]
+    loss_mask: Tensor  # the original masks, joined ([1, T], host)
+
+
+def join_micro_batches(micro_batches: list[MicroBatch], max_tokens: int = MERGE_MAX_TOKENS) -> list[JoinedRows]:
+    """Consecutive micro-batches with the same temperature joined into rows of at most `max_tokens` tokens.
+
+    The reference runs one forward / backward per micro-batch because of memory (gradient accumulation,
+    src/prime_rl/trainer/rl/train.py:271-310); with 288 GB a whole step's rows fit at once, and at 16 K tokens
+    the GEMMs and element-wise kernels of a 0.6B model run at twice the rate they reach at 2 K.  In token mode
+    the result is the same sum: samples never attend across a position restart, the loss is a sum over tokens
+    under one normaliser for the whole step.  One token per row needs care: the reference scores the FIRST token
+    of a row against all-zero logits (loss.py:51-58), while in a joined row it would be scored against the
+    previous row's last logits.  Those tokens are masked out here and put back by `restore_row_starts`."""
+    out: list[JoinedRows] = []
+    group: list[MicroBatch] = []
+
+    def flush() -> None:
+        if not group:
+            return
+        lengths = [int(mb["input_ids"].shape[1]) for mb in group]
+        starts = [0]
+        for n in lengths[:-1]:
+            starts.append(starts[-1] + n)
+        joined = {k: torch.cat([mb[k] for mb in group], dim=1) for k in
+                  ("input_ids", "position_ids", "advantages", "logprobs", "loss_mask")}
+        joined["temperature"] = group[0]["temperature"]
+        original = joined["loss_mask"]
+        if len(group) > 1:
+            joined["loss_mask"] = original.clone()
+            joined["loss_mask"][0, starts[1:]] = False
+        out.append(JoinedRows(joined, starts, lengths, original))
+        group.clear()
+
+    tokens = 0
+    for mb in micro_batches:
+        n = int(mb["input_ids"].shape[1])
+        fits = mb["input_ids"].shape[0] == 1 and group and group[0]["temperature"] == mb["temperature"] \
+            and tokens + n <= max_tokens
+        if not fits:
+            flush()
+            tokens = 0
+        group.append(mb)
+        tokens += n
+        if mb["input_ids"].shape[0] != 1:
+            flush()
+            tokens = 0
+    flush()
+    return out
+
+
+def join_per_row(pieces: list[Tensor], rows: list[JoinedRows]) -> list[Tensor]:
+    """Per-micro-batch [1, T_i] tensors joined the way `rows` joined the micro-batches."""
+    out, a = [], 0
+    for r in rows:
+        k = len(r.lengths)
+        out.append(pieces[a] if k == 1 else torch.cat(pieces[a : a + k], dim=1))
+        a += k
+    return out
+
+
+def restore_row_starts(rows: JoinedRows, mb: dict[str, Any], aux: dict[str, Tensor], loss_config: LossConfig,
+                       vocab: int, inv_scale: float) -> Tensor:
+    """Give the first token of every joined row but the first what the reference gives it: log-probability
+    -ln V and entropy ln V (all-zero logits), the ratio and loss term that follow from those, no gradient (a
+    constant has none).  `mb` is the joined row on the device, `aux` what `policy_loss` returned for it (fixed in
+    place).  Returns the losses of the original rows [n_rows], each under the step's normaliser `1 / inv_scale`
+    (what the reference logs as one `loss` per micro-batch)."""
+    dev = aux["logprobs"].device
+    mask = rows.loss_mask.to(dev, non_blocking=True).reshape(-1)
+    if len(rows.starts) > 1:
+        idx = torch.tensor(rows.starts[1:], dtype=torch.int64).to(dev, non_blocking=True)
+        ln_v = float(torch.log(torch.tensor(float(vocab), dtype=torch.float32)))
+        old = mb["logprobs"].reshape(-1)[idx].float()
+        ratio = torch.exp(-ln_v - old)
+        aux["logprobs"].reshape(-1)[idx] = -ln_v
+        aux["entropy"].reshape(-1)[idx] = ln_v
+        aux["importance_ratio"][idx] = ratio
+        aux["clipped_importance_ratio"][idx] = torch.clamp(ratio, max=float(loss_config.clip_ratio))
+        aux["is_clipped"][idx] = (ratio > float(loss_config.clip_ratio)).float()
+    term = -(aux["clipped_importance_ratio"] * mb["advantages"].reshape(-1).float()) * mask * inv_scale
+    per_row, a = [], 0
+    for n in rows.lengths:
+        per_row.append(term[a : a + n].sum())
+        a += n
+    return torch.stack(per_row)
+
+
 def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, micro_batches: list[MicroBatch],
                loss_config: LossConfig, max_norm: float = 1.0, device: torch.device | str = "cuda",
                scheduler: Any = None, samples: int | None = None,
-               recomputed_errors: list[Tensor] | None = None) -> StepResult:
+               recomputed_errors: list[Tensor] | None = None, join_tokens: int = MERGE_MAX_TOKENS) -> StepResult:
     """One optimizer step over this rank's micro-batches
     (src/prime_rl/trainer/rl/train.py:259-364).  `recomputed_errors` are the
     per-micro-batch tensors `recompute_logprobs` returned; they are logged as
-    `recomputed_logprob_error` (train.py:316-318)."""
+    `recomputed_logprob_error` (train.py:316-318).  In token mode consecutive
+    micro-batches are joined into rows of up to `join_tokens` tokens and run as
+    one (`join_micro_batches`; 0 keeps them apart)."""
     t0 = time.perf_counter()
     loss_scale = local_loss_scale(micro_batches, loss_config)
     tensors = Tensors()
     tokens = 0
-    for step_idx, host_mb in enumerate(micro_batches):
-        last = step_idx == len(micro_batches) - 1
+    rows = join_micro_batches(micro_batches, join_tokens) if loss_config.ratio_type == "token" and join_tokens > 0 \
+        else None
+    units = [r.micro_batch for r in rows] if rows is not None else micro_batches
+    if rows is not None and recomputed_errors is not None:
+        recomputed_errors = join_per_row(recomputed_errors, rows)
+    for step_idx, host_mb in enumerate(units):
+        last = step_idx == len(units) - 1
         if hasattr(model, "set_requires_all_reduce"):
             model.set_requires_all_reduce(last)
         if getattr(model, "_prl_keep_gathered", False) and hasattr(model, "set_requires_gradient_sync"):
@@ -193,15 +298,20 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, micro_batches
             model.set_reshard_after_backward(last)
         mb = to_device(host_mb, device)
         logits = forward(model, mb["input_ids"], mb["position_ids"], attention_plan(host_mb, device))
+        vocab = int(logits.shape[-1])
         loss, aux = policy_loss(logits, mb["input_ids"], mb["position_ids"], mb["advantages"], mb["logprobs"],
                                 mb["loss_mask"], mb["temperature"], loss_config, loss_scale, skip_masked=True)
         del logits
         loss.backward(unit_gradient(loss.device))
-        mask = mb["loss_mask"]
+        if rows is not None:
+            losses = restore_row_starts(rows[step_idx], mb, aux, loss_config, vocab, 1.0 / max(float(loss_scale), 1.0))
+            mask = rows[step_idx].loss_mask.to(device, non_blocking=True)
+        else:
+            losses, mask = loss.detach().reshape(1), mb["loss_mask"]
         tensors.add("probs", aux["logprobs"], mask, exp=True)
         tensors.add("old_probs", mb["logprobs"], mask, exp=True)
         tensors.add("entropy", aux["entropy"], mask)
-        tensors.add("loss", loss.detach().reshape(1))
+        tensors.add("loss", losses)
         if recomputed_errors is not None:
             tensors.add("recomputed_logprob_error", recomputed_errors[step_idx], mask)
         if loss_config.ratio_type == "token":
@@ -222,7 +332,7 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, micro_batches
         # synthetic loader that is the micro-batch size
         samples = len(micro_batches)
     return StepResult(loss=stats.get("loss/mean", float("nan")), grad_norm=float(grad_norm), stats=stats,
-                      seconds=seconds, tokens=tokens, samples=samples)
+                      seconds=seconds, tokens=tokens, samples=samples, passes=len(units))
 
 
 @torch.no_grad()

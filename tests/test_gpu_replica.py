@@ -79,8 +79,8 @@ def test_accumulate_kernel_against_torch(dtype):
                               C.ptr(acc), None) != 0
 
 
-@pytest.mark.parametrize("ratio_type", ["token", "sequence"])
-def test_fp32_replica_step_matches_cpu_model_with_oracle_loss(ratio_type):
+@pytest.mark.parametrize("ratio_type,join", [("token", 0), ("sequence", 0), ("token", 16384)])
+def test_fp32_replica_step_matches_cpu_model_with_oracle_loss(ratio_type, join):
     cfg = tiny_config()
     cpu_model = T.get_model(cfg, "cpu", torch.float32, seed=3)
     gpu_model = copy.deepcopy(cpu_model).to(DEV)
@@ -103,8 +103,9 @@ def test_fp32_replica_step_matches_cpu_model_with_oracle_loss(ratio_type):
 
     rep = Replica(gpu_model, lambda m: torch.optim.SGD(m.parameters(), lr=1.0), compute_dtype=torch.float32)
     before = rep.state.master.detach().clone()
-    res = rep.train_step(mbs, loss_cfg, max_norm=1e9)
-    assert rep.eager_runs == 1 and rep.replays == 3
+    res = rep.train_step(mbs, loss_cfg, max_norm=1e9, join_tokens=join)
+    # apart: eager, capture + replay, replay, replay; joined: the four rows are one row of 256 tokens
+    assert (rep.eager_runs, rep.replays) == ((1, 3) if join == 0 else (1, 0))
     assert abs(res.grad_norm - cpu_norm) <= 2e-4 * cpu_norm
     assert abs(res.stats["loss/mean"] - sum(cpu_losses) / len(cpu_losses)) <= 1e-4
     step = before - rep.state.master.detach()  # SGD with lr 1: the step is the gradient
@@ -116,14 +117,14 @@ def test_fp32_replica_step_matches_cpu_model_with_oracle_loss(ratio_type):
         assert torch.equal(p.detach().reshape(-1), rep.state.master.detach()[o : o + p.numel()])
 
 
-def _three_steps(graphs, batches, loss_cfg, max_graphs=4):
+def _three_steps(graphs, batches, loss_cfg, max_graphs=4, join_tokens=0):
     cfg = tiny_config(vocab=4096)
     model = T.get_model(cfg, DEV, torch.float32, seed=11)
     rep = Replica(model, lambda m: torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=0.01), graphs=graphs,
                   max_graphs=max_graphs)
     out = []
     for mbs in batches:
-        res = rep.train_step(mbs, loss_cfg, max_norm=1.0)
+        res = rep.train_step(mbs, loss_cfg, max_norm=1.0, join_tokens=join_tokens)
         out.append((res.grad_norm, res.stats, rep.state.flat16.clone(), rep.state.master.detach().clone()))
     return rep, out
 
@@ -161,6 +162,32 @@ def test_ragged_rows_of_several_shapes_and_graph_eviction():
         for k in s0:
             assert s1[k] == pytest.approx(s0[k], rel=1e-5, abs=1e-7), k
         torch.testing.assert_close(m1, m0, rtol=1e-5, atol=1e-7)
+
+
+def test_joined_rows_give_the_step_of_the_separate_rows():
+    """A step over rows joined end to end (one forward / backward) against the same step row by row: statistics
+    (the per-row losses among them), gradient norm and updated weights.  Every token is unmasked here, the first
+    token of every row included, which is the case `restore_row_starts` exists for."""
+    gen = torch.Generator().manual_seed(21)
+    loss_cfg = prl.LossConfig()
+    batches = []
+    for _ in range(3):
+        mbs = rows(gen, 5, [32, 32, 32, 32], 4096)
+        for mb in mbs:
+            mb["loss_mask"] = torch.ones_like(mb["loss_mask"])
+            mb["logprobs"] = -8.3 + 0.2 * torch.randn(mb["logprobs"].shape, generator=gen)  # near -ln V: row starts unclipped
+        batches.append(mbs)
+    apart, want = _three_steps(True, batches, loss_cfg, join_tokens=0)
+    joined, got = _three_steps(True, batches, loss_cfg, join_tokens=16384)
+    assert joined.replays == 2 and joined.eager_runs == 1 and not joined.capture_errors  # one row of 640 tokens per step
+    for i, ((n0, s0, f0, m0), (n1, s1, f1, m1)) in enumerate(zip(want, got)):
+        assert n1 == pytest.approx(n0, rel=5e-3)
+        assert s1.keys() == s0.keys()
+        for k in s0:
+            assert s1[k] == pytest.approx(s0[k], rel=5e-3, abs=1e-6), k
+        # AdamW moves every weight by about lr per step; bf16 rounding in another summation order flips the sign
+        # of the update only where the gradient is at the noise level
+        assert (m1 - m0).norm().item() <= 0.3 * 1e-3 * m0.numel() ** 0.5 * (i + 1)
 
 
 def test_eligibility():

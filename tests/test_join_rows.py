@@ -1,0 +1,46 @@
+"""Joining a step's micro-batches into longer rows (host logic of trainer.join_micro_batches)."""
+
+import torch
+
+from prime_rl_cse_amd import trainer as T
+
+
+def row(n, temperature=1.0, seed=0):
+    gen = torch.Generator().manual_seed(seed + n)
+    return {
+        "input_ids": torch.randint(0, 50, (1, n), generator=gen),
+        "position_ids": torch.arange(n)[None],
+        "advantages": torch.randn(1, n, generator=gen),
+        "logprobs": torch.randn(1, n, generator=gen),
+        "loss_mask": torch.ones(1, n, dtype=torch.bool),
+        "temperature": temperature,
+    }
+
+
+def test_rows_are_joined_up_to_the_token_limit_and_only_at_one_temperature():
+    mbs = [row(10), row(20), row(30), row(25, temperature=0.6), row(5, temperature=0.6), row(7)]
+    joined = T.join_micro_batches(mbs, max_tokens=40)
+    assert [r.lengths for r in joined] == [[10, 20], [30], [25, 5], [7]]
+    assert [r.starts for r in joined] == [[0, 10], [0], [0, 25], [0]]
+    first = joined[0]
+    assert first.micro_batch["input_ids"].shape == (1, 30)
+    assert torch.equal(first.micro_batch["input_ids"], torch.cat([mbs[0]["input_ids"], mbs[1]["input_ids"]], dim=1))
+    assert first.micro_batch["position_ids"][0, 10] == 0  # the second row restarts: attention keeps them apart
+    # the first token of every row but the first is masked out of the joined row, not out of the original mask
+    assert first.loss_mask.all() and not first.micro_batch["loss_mask"][0, 10]
+    assert int(first.micro_batch["loss_mask"].sum()) == 29 and mbs[1]["loss_mask"].all()
+    assert joined[2].micro_batch["temperature"] == 0.6
+    # nothing to join: the micro-batch itself, mask untouched
+    assert joined[1].micro_batch["loss_mask"].all() and joined[1].micro_batch["input_ids"] is not None
+
+
+def test_rows_with_a_batch_dimension_stay_alone_and_pieces_follow_the_rows():
+    two = row(8)
+    two = {k: (torch.cat([v, v]) if isinstance(v, torch.Tensor) else v) for k, v in two.items()}
+    mbs = [row(4), two, row(5), row(6)]
+    joined = T.join_micro_batches(mbs, max_tokens=100)
+    assert [r.lengths for r in joined] == [[4], [8], [5, 6]]
+    pieces = [torch.full((1, n), float(i)) for i, n in enumerate((4, 8, 5, 6))]
+    out = T.join_per_row(pieces, joined)
+    assert [p.shape[1] for p in out] == [4, 8, 11] and out[2][0, 4] == 2.0 and out[2][0, 5] == 3.0
+    assert T.join_micro_batches([], 10) == []
