@@ -242,7 +242,7 @@ def trainer_measure(dev, world: int, steps: int, warmup: int, cpu: bool, cpu_sec
         "loss": res.loss,
         "grad_norm": res.grad_norm,
         "precision": "bf16 compute, fp32 master weights and gradient reduction, fp32 loss math",
-        "attention": "short-sample MFMA kernels (csrc/attn_short.hip)" if impl != "hf" else "sdpa",
+        "attention": "sdpa" if os.environ.get("PRL_ATTN_SHORT") == "0" else "short-sample MFMA kernels (csrc/attn_short.hip)",
         "micro_batches_per_step": len(batches[0]),
         "forward_backward_passes_per_step": res.passes,
         "blocks": "transformers Qwen3" + (f", modules on HIP kernels: {fused_modules}" if fused_modules else ""),

@@ -281,10 +281,9 @@ __global__ __launch_bounds__(kAThreads) void k_attn_short_bwd_dkv(AttnView q, At
                                                                   const int32_t* cu, int Hkv, int G, int64_t T,
                                                                   float c, float scale) {
   extern __shared__ __align__(16) uint16_t lds[];
-  uint16_t* Qs = lds;
-  uint16_t* Os = lds + kAImg;  // dO
-  float* row_lse = reinterpret_cast<float*>(lds + 2 * kAImg);
-  float* row_delta = row_lse + kAL;
+  // two query heads at a time: Q and dO of both are staged in one go (4 images), so a group of two heads costs
+  // one round of loads and two barriers instead of two rounds and four
+  float* row_stats = reinterpret_cast<float*>(lds + 4 * kAImg);  // [2 heads][lse, delta][128]
   const int s = blockIdx.x / Hkv, hkv = blockIdx.x % Hkv;
   int64_t start;
   int len;
@@ -299,43 +298,52 @@ __global__ __launch_bounds__(kAThreads) void k_attn_short_bwd_dkv(AttnView q, At
   }
   const int qtiles = (len + 31) >> 5;
   f32x16 dkt[4] = {}, dvt[4] = {};
-  for (int g = 0; g < G; ++g) {
-    const int hq = hkv * G + g;
-    __syncthreads();  // the previous head's images are no longer read
-    stage_rows(Qs, q, start, len, hq);
-    stage_rows(Os, dout, start, len, hq);
-    if (threadIdx.x < kAL) {
-      const bool in = (int)threadIdx.x < len;
-      row_lse[threadIdx.x] = in ? lse2[(int64_t)hq * T + start + threadIdx.x] : 0.0f;
-      row_delta[threadIdx.x] = in ? delta[(int64_t)hq * T + start + threadIdx.x] : 0.0f;
+  for (int g0 = 0; g0 < G; g0 += 2) {
+    const int heads = G - g0 < 2 ? G - g0 : 2;
+    __syncthreads();  // the previous pair's images are no longer read
+    for (int j = 0; j < heads; ++j) {
+      const int hq = hkv * G + g0 + j;
+      stage_rows(lds + (2 * j) * kAImg, q, start, len, hq);
+      stage_rows(lds + (2 * j + 1) * kAImg, dout, start, len, hq);
+      if (threadIdx.x < kAL) {
+        const bool in = (int)threadIdx.x < len;
+        row_stats[(2 * j) * kAL + threadIdx.x] = in ? lse2[(int64_t)hq * T + start + threadIdx.x] : 0.0f;
+        row_stats[(2 * j + 1) * kAL + threadIdx.x] = in ? delta[(int64_t)hq * T + start + threadIdx.x] : 0.0f;
+      }
     }
     __syncthreads();
     if (32 * w < len) {  // wave-uniform: this wave has keys
+      for (int j = 0; j < heads; ++j) {
+        const uint16_t* Qs = lds + (2 * j) * kAImg;
+        const uint16_t* Os = lds + (2 * j + 1) * kAImg;  // dO
+        const float* row_lse = row_stats + (2 * j) * kAL;
+        const float* row_delta = row_stats + (2 * j + 1) * kAL;
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {  // query tiles; causal: only those at or after the wave's keys
-        if (mt >= w && mt < qtiles) {
-          f32x16 sa = {}, dp = {};
+        for (int mt = 0; mt < 4; ++mt) {  // query tiles; causal: only those at or after the wave's keys
+          if (mt >= w && mt < qtiles) {
+            f32x16 sa = {}, dp = {};
 #pragma unroll
-          for (int kk = 0; kk < 8; ++kk) {
-            sa = mfma(frag_rows(Qs, 32 * mt + r, kk, h), kf[kk], sa);  // S: rows = queries, lane = key
-            dp = mfma(frag_rows(Os, 32 * mt + r, kk, h), vf[kk], dp);  // dP = dO V^T
-          }
-          f32x16 pa, ds;
+            for (int kk = 0; kk < 8; ++kk) {
+              sa = mfma(frag_rows(Qs, 32 * mt + r, kk, h), kf[kk], sa);  // S: rows = queries, lane = key
+              dp = mfma(frag_rows(Os, 32 * mt + r, kk, h), vf[kk], dp);  // dP = dO V^T
+            }
+            f32x16 pa, ds;
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int query = 32 * mt + acc_row(i, h);
-            const bool valid = key <= query && query < len && key < len;
-            const float p = valid ? __builtin_amdgcn_exp2f(fmaf(sa[i], c, -row_lse[query])) : 0.0f;
-            pa[i] = p;
-            ds[i] = p * (dp[i] - row_delta[query]) * scale;
-          }
+            for (int i = 0; i < 16; ++i) {
+              const int query = 32 * mt + acc_row(i, h);
+              const bool valid = key <= query && query < len && key < len;
+              const float p = valid ? __builtin_amdgcn_exp2f(fmaf(sa[i], c, -row_lse[query])) : 0.0f;
+              pa[i] = p;
+              ds[i] = p * (dp[i] - row_delta[query]) * scale;
+            }
 #pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            const bf16x8 pf = acc_frag(pa, s2), df = acc_frag(ds, s2);
+            for (int s2 = 0; s2 < 2; ++s2) {
+              const bf16x8 pf = acc_frag(pa, s2), df = acc_frag(ds, s2);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-              dvt[dt] = mfma(frag_cols(Os, 32 * dt, 32 * mt, s2, lane), pf, dvt[dt]);  // dV^T += dO^T P
-              dkt[dt] = mfma(frag_cols(Qs, 32 * dt, 32 * mt, s2, lane), df, dkt[dt]);  // dK^T += Q^T dS
+              for (int dt = 0; dt < 4; ++dt) {
+                dvt[dt] = mfma(frag_cols(Os, 32 * dt, 32 * mt, s2, lane), pf, dvt[dt]);  // dV^T += dO^T P
+                dkt[dt] = mfma(frag_cols(Qs, 32 * dt, 32 * mt, s2, lane), df, dkt[dt]);  // dK^T += Q^T dS
+              }
             }
           }
         }
@@ -367,7 +375,7 @@ static bool view_ok(const void* p, int64_t ts, int64_t hs) {
 
 constexpr size_t kFwdLds = 2 * kAImg * sizeof(uint16_t);
 constexpr size_t kDqLds = 2 * kAImg * sizeof(uint16_t);
-constexpr size_t kDkvLds = 2 * kAImg * sizeof(uint16_t) + 2 * kAL * sizeof(float);
+constexpr size_t kDkvLds = 4 * kAImg * sizeof(uint16_t) + 4 * kAL * sizeof(float);
 
 // The kernels use more than the 64 KB of LDS a launch gets by default; raised once per process and device.
 static int raise_lds_limits() {

@@ -198,6 +198,18 @@ static int norm_blocks(int64_t rows, int lpr, int cap = kNormMaxBlocks) {
   const int64_t want = (rows + rpb - 1) / rpb;
   return (int)(want < cap ? (want > 0 ? want : 1) : cap);
 }
+// Backward: every workgroup leaves one partial row for the weight-gradient finish, so few workgroups are
+// better for short inputs (tools/tune_norm.py, 2048-token rows); long inputs (16 K-token joined rows) need
+// more of them in flight to reach the memory rate: at least 8 row steps per workgroup, between the tuned cap
+// and the forward's.
+static int norm_bwd_blocks(int64_t rows, int lpr) {
+  const int64_t rpb = kNormThreads / lpr;
+  const int64_t want = (rows + rpb - 1) / rpb;
+  int64_t cap = want / 8;
+  if (cap < kNormMaxBlocks) cap = kNormMaxBlocks;
+  if (cap > kNormFwdMaxBlocks) cap = kNormFwdMaxBlocks;
+  return norm_blocks(rows, lpr, (int)cap);
+}
 static int norm_lpr(int64_t H, int ve) { return H / ve <= 16 ? 16 : 64; }
 static int norm_nv(int64_t H, int ve, int lpr) { return (int)((H / ve + lpr - 1) / lpr); }
 
@@ -215,7 +227,7 @@ extern "C" int prl_rmsnorm_supported(int dtype, int64_t H) {
 
 extern "C" size_t prl_rmsnorm_bwd_workspace_bytes(int dtype, int64_t rows, int64_t H) {
   const int ve = dtype == PRL_F32 ? 4 : 8;
-  return (size_t)norm_blocks(rows, norm_lpr(H, ve)) * (size_t)H * sizeof(float);
+  return (size_t)norm_bwd_blocks(rows, norm_lpr(H, ve)) * (size_t)H * sizeof(float);
 }
 
 #define PRL_NORM_DISPATCH(KERNEL, ...)                                    \
@@ -296,7 +308,7 @@ extern "C" int prl_rmsnorm_bwd(const void* x, int64_t x_row_stride, const void* 
   PRL_REQUIRE((reinterpret_cast<uintptr_t>(w) & 15) == 0, "rmsnorm_bwd: w must be 16-byte aligned");
   const int es = dtype == PRL_F32 ? 4 : 2, ve = 16 / es;
   const int lpr = norm_lpr(H, ve), nv = norm_nv(H, ve, lpr);
-  const int nblk = norm_blocks(rows, lpr);
+  const int nblk = norm_bwd_blocks(rows, lpr);
   PRL_REQUIRE(workspace && workspace_bytes >= (size_t)nblk * H * sizeof(float),
               "rmsnorm_bwd: workspace of %zu bytes needed (prl_rmsnorm_bwd_workspace_bytes)",
               (size_t)nblk * H * sizeof(float));
