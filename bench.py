@@ -196,7 +196,9 @@ def trainer_measure(dev, world: int, steps: int, warmup: int, cpu: bool, cpu_sec
     if impl in ("graphed", "replica"):  # whole model per GPU, micro-batches from HIP graphs ("replica": eagerly)
         from prime_rl_cse_amd.replica import Replica
 
-        replica = Replica(model, lambda m: torch.optim.AdamW(m.parameters(), lr=1e-6, weight_decay=0.01, fused=True),
+        from prime_rl_cse_amd.optim import FlatAdamW
+
+        replica = Replica(model, lambda m: FlatAdamW(m.parameters(), lr=1e-6, weight_decay=0.01),
                           graphs=impl == "graphed")
         opt = replica.optimizer
 

@@ -312,6 +312,18 @@ int prl_attn_short_bwd(const void* q, const int64_t* q_strides, const void* k, c
                        int32_t q_heads, int32_t kv_heads, float scale, void* stream);
 
 /*
+ * AdamW over one flat fp32 shard, fused with what surrounds it at the end of a step: param, exp_avg, exp_avg_sq
+ * and grad are fp32 [n] (n a multiple of 4); every gradient is first multiplied by grad_scale[0] (DEVICE
+ * memory, NULL = 1: the clipping factor of clip_grad_norm_, never copied to the host); `compute_copy`
+ * (bf16 or fp32 [n], may be NULL) receives the new weights for the next forward; zero_grad != 0 clears grad.
+ * The update rule is torch.optim.AdamW's, which the reference runs after clip_grad_norm_
+ * (src/prime_rl/trainer/optim.py:19-25, src/prime_rl/trainer/rl/train.py:336-342); `step` counts from 1.
+ */
+int prl_adamw_flat(float* param, float* grad, float* exp_avg, float* exp_avg_sq, void* compute_copy, int copy_dtype,
+                   int64_t n, const float* grad_scale, int zero_grad, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int64_t step, void* stream);
+
+/*
  * Group-relative advantages: B rewards in consecutive groups of G.  Replaces
  * compute_advantages (src/prime_rl/orchestrator/advantage.py:71-103) for the
  * four kinds of its REGISTRY (:63-68).  `lengths` (int64 [B], completion

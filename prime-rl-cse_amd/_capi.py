@@ -93,6 +93,11 @@ SIGNATURES = {
         c_int,
         [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p],
     ),
+    "prl_adamw_flat": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int, c_float, c_float, c_float,
+         c_float, c_float, c_int64, c_void_p],
+    ),
     "prl_rope_supported": (c_int, [c_int, c_int64]),
     "prl_rope": (
         c_int,

@@ -16,9 +16,63 @@ from torch import nn
 from torch.optim.lr_scheduler import LambdaLR, LRScheduler
 
 
-def setup_optimizer(config: Any, model: nn.Module, fused: bool | None = None) -> torch.optim.Optimizer:
+class FlatAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW's update over ONE flat fp32 parameter on the GPU (the master shard of
+    `replica.FlatState`), as one HIP launch that also applies the clipping factor, writes the compute copy of the
+    new weights and clears the gradient (`prl_adamw_flat`).  Learning-rate schedulers drive it like any optimizer."""
+
+    def __init__(self, params: Any, lr: float = 1e-3, betas: tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        if len(self.param_groups) != 1 or len(self.param_groups[0]["params"]) != 1:
+            raise ValueError("FlatAdamW takes exactly one (flat) parameter")
+
+    @torch.no_grad()
+    def step_flat(self, grad: torch.Tensor, grad_scale: torch.Tensor | None = None,
+                  compute_copy: torch.Tensor | None = None, zero_grad: bool = False) -> None:
+        """One step with `grad` (fp32, same size as the parameter) times `grad_scale` (a 1-element device tensor,
+        or None); `compute_copy` receives the new weights in its own dtype; `zero_grad` clears `grad`."""
+        from . import _capi as C
+
+        group = self.param_groups[0]
+        p = group["params"][0]
+        dev = C.require_device(p, grad, grad_scale, compute_copy)
+        if p.dtype != torch.float32 or grad.dtype != torch.float32 or grad.numel() != p.numel() \
+                or not (p.is_contiguous() and grad.is_contiguous()):
+            raise ValueError("FlatAdamW: parameter and gradient must be contiguous fp32 tensors of one size")
+        if compute_copy is not None and (compute_copy.numel() != p.numel() or not compute_copy.is_contiguous()):
+            raise ValueError("FlatAdamW: the compute copy must be contiguous and as long as the parameter")
+        state = self.state[p]
+        if not state:
+            state["step"] = 0
+            state["exp_avg"] = torch.zeros_like(p)
+            state["exp_avg_sq"] = torch.zeros_like(p)
+        state["step"] += 1
+        self._opt_called = True  # what torch's schedulers look at to tell a step has been taken
+        b1, b2 = group["betas"]
+        with C.on_device(dev), C.timed("prl_adamw_flat", dev):
+            C.check(
+                C.load().prl_adamw_flat(C.ptr(p), C.ptr(grad), C.ptr(state["exp_avg"]), C.ptr(state["exp_avg_sq"]),
+                                        C.ptr(compute_copy), 0 if compute_copy is None else C.dtype_code(compute_copy),
+                                        p.numel(), C.ptr(grad_scale), int(zero_grad), float(group["lr"]), float(b1),
+                                        float(b2), float(group["eps"]), float(group["weight_decay"]), state["step"],
+                                        C.stream_ptr(dev)),
+                "prl_adamw_flat",
+            )
+
+    @torch.no_grad()
+    def step(self, closure: Any = None) -> None:  # the plain Optimizer protocol: the parameter's own .grad
+        p = self.param_groups[0]["params"][0]
+        if p.grad is not None:
+            self.step_flat(p.grad)
+
+
+def setup_optimizer(config: Any, model: nn.Module, fused: bool | None = None, flat: bool = False) -> torch.optim.Optimizer:
     """The optimizer of src/prime_rl/trainer/optim.py:9-38 over `model.parameters()`.  `fused=True` asks torch for
-    its one-kernel AdamW (same update rule; worth it over one large flat parameter)."""
+    its one-kernel AdamW (same update rule); `flat=True` (one flat fp32 parameter on the GPU) gives `FlatAdamW`."""
+    if config.type == "adamw" and flat:
+        return FlatAdamW(model.parameters(), lr=config.lr, weight_decay=config.weight_decay,
+                         betas=(config.betas1, config.betas2))
     if config.type == "sgd":
         return torch.optim.SGD(model.parameters(), lr=config.lr, weight_decay=config.weight_decay,
                                momentum=config.momentum, nesterov=config.nesterov)

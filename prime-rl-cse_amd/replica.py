@@ -117,8 +117,18 @@ class FlatState:
         if self.world > 1:
             dist.all_reduce(sq, group=self.group)
         norm = sq.sqrt()
-        if max_norm is not None:
-            grad.mul_(torch.clamp(max_norm / (norm + 1e-6), max=1.0))
+        coef = torch.clamp(max_norm / (norm + 1e-6), max=1.0).reshape(1) if max_norm is not None else None
+        if hasattr(optimizer, "step_flat"):
+            # clipping, the update, the new compute copy and (one rank) the clearing of the sums in one launch
+            if self.world > 1:
+                optimizer.step_flat(grad, coef, self._shard16)
+                dist.all_gather_into_tensor(self.flat16, self._shard16, group=self.group)
+                self.acc32.zero_()
+            else:
+                optimizer.step_flat(grad, coef, self.flat16, zero_grad=True)
+            return norm
+        if coef is not None:
+            grad.mul_(coef)
         self.master.grad = grad
         optimizer.step()
         self.master.grad = None

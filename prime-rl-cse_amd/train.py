@@ -128,8 +128,7 @@ def _train(config: RLTrainerConfig, world: Any, device: torch.device, mesh: Any)
         reason = eligible(T.get_model(model_config_of(config), "meta"), config.optim.type, config.model.ac is not None)
         if reason is None:
             model, model_cfg = build_model(config, device, mesh, shard=False)
-            fused = True if config.optim.type == "adamw" else None
-            replica = Replica(model, lambda m: setup_optimizer(config.optim, m, fused=fused))
+            replica = Replica(model, lambda m: setup_optimizer(config.optim, m, flat=True))
             log("model.compile: whole model per GPU, micro-batches replayed from HIP graphs")
         else:
             log(f"model.compile ignored ({reason}); FSDP2 as usual")

@@ -120,7 +120,9 @@ def test_fp32_replica_step_matches_cpu_model_with_oracle_loss(ratio_type, join):
 def _three_steps(graphs, batches, loss_cfg, max_graphs=4, join_tokens=0):
     cfg = tiny_config(vocab=4096)
     model = T.get_model(cfg, DEV, torch.float32, seed=11)
-    rep = Replica(model, lambda m: torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=0.01), graphs=graphs,
+    from prime_rl_cse_amd.optim import FlatAdamW
+
+    rep = Replica(model, lambda m: FlatAdamW(m.parameters(), lr=1e-3, weight_decay=0.01), graphs=graphs,
                   max_graphs=max_graphs)
     out = []
     for mbs in batches:
@@ -188,6 +190,41 @@ def test_joined_rows_give_the_step_of_the_separate_rows():
         # AdamW moves every weight by about lr per step; bf16 rounding in another summation order flips the sign
         # of the update only where the gradient is at the noise level
         assert (m1 - m0).norm().item() <= 0.3 * 1e-3 * m0.numel() ** 0.5 * (i + 1)
+
+
+def test_flat_adamw_takes_torch_adamw_steps():
+    from prime_rl_cse_amd.optim import FlatAdamW
+
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    n = 4 * 25_003
+    p0 = torch.randn(n, generator=gen, device=DEV)
+    ref = torch.nn.Parameter(p0.clone())
+    mine = torch.nn.Parameter(p0.clone())
+    kw = dict(lr=3e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
+    want = torch.optim.AdamW([ref], **kw)
+    got = FlatAdamW([mine], **kw)
+    sched = torch.optim.lr_scheduler.LambdaLR(got, lambda step: 1.0 / (1 + step))  # schedulers drive it
+    sched_ref = torch.optim.lr_scheduler.LambdaLR(want, lambda step: 1.0 / (1 + step))
+    copy16 = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    for step in range(4):
+        g = torch.randn(n, generator=gen, device=DEV) * (10.0 ** (step - 2))
+        scale = torch.tensor([0.37 if step % 2 else 1.0], device=DEV)
+        ref.grad = g * scale
+        want.step()
+        sched_ref.step()
+        acc = g.clone()
+        got.step_flat(acc, scale, copy16, zero_grad=step != 2)
+        sched.step()
+        torch.testing.assert_close(mine.detach(), ref.detach(), rtol=2e-6, atol=1e-7)
+        assert torch.equal(copy16, mine.detach().to(torch.bfloat16))
+        assert (not acc.any()) if step != 2 else torch.equal(acc, g)
+    for key in ("exp_avg", "exp_avg_sq"):
+        a, b = got.state[mine][key], want.state[ref][key]
+        torch.testing.assert_close(a, b, rtol=2e-6, atol=1e-6 * b.abs().max().item())  # sums of unequal magnitudes
+    mine.grad = torch.ones_like(mine)
+    got.step()  # the plain protocol
+    with pytest.raises(ValueError):
+        FlatAdamW([mine, ref])
 
 
 def test_eligibility():
