@@ -324,6 +324,28 @@ int prl_adamw_flat(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
                    float weight_decay, int64_t step, void* stream);
 
 /*
+ * Query / key RMSNorm over every head followed by the rotary embedding, reading the query and key blocks of a
+ * stacked projection output y [T][(q_heads + k_heads [+ v_heads]) * 128] (row pitch y_pitch, in elements) and
+ * writing q_out [T][q_heads][128] and k_out [T][k_heads][128] (contiguous) plus rstd [T][q_heads + k_heads].
+ * The backward takes the gradients of q_out and k_out ({token stride, head stride} in elements, HOST arrays)
+ * and writes the gradient with respect to y's query and key blocks INTO gy (same layout as y, pitch gy_pitch),
+ * and gw [256] = the two norm weights' gradients (query's, then key's), in y's dtype.  cos / sin are
+ * [T][128] with a token stride.  Head dimension 128 only.  These are the steps of the transformers attention
+ * block between its projections and its attention call; the reference's switch for fused block kernels is
+ * `model.impl = "liger_kernel"` (src/prime_rl/trainer/model.py:74-75).
+ */
+int prl_qk_norm_rope_supported(int dtype, int64_t head_dim);
+size_t prl_qk_norm_rope_bwd_workspace_bytes(int dtype, int64_t T, int64_t q_heads, int64_t k_heads);
+int prl_qk_norm_rope_fwd(const void* y, int64_t y_pitch, const void* wq, const void* wk, const void* cos_,
+                         const void* sin_, int64_t cs_token_stride, void* q_out, void* k_out, float* rstd, int dtype,
+                         int64_t T, int64_t q_heads, int64_t k_heads, float eps, void* stream);
+int prl_qk_norm_rope_bwd(const void* gq, const int64_t* gq_strides, const void* gk, const int64_t* gk_strides,
+                         const void* y, int64_t y_pitch, const void* wq, const void* wk, const float* rstd,
+                         const void* cos_, const void* sin_, int64_t cs_token_stride, void* gy, int64_t gy_pitch,
+                         void* gw, void* workspace, size_t workspace_bytes, int dtype, int64_t T, int64_t q_heads,
+                         int64_t k_heads, void* stream);
+
+/*
  * Group-relative advantages: B rewards in consecutive groups of G.  Replaces
  * compute_advantages (src/prime_rl/orchestrator/advantage.py:71-103) for the
  * four kinds of its REGISTRY (:63-68).  `lengths` (int64 [B], completion

@@ -98,6 +98,19 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int, c_float, c_float, c_float,
          c_float, c_float, c_int64, c_void_p],
     ),
+    "prl_qk_norm_rope_supported": (c_int, [c_int, c_int64]),
+    "prl_qk_norm_rope_bwd_workspace_bytes": (c_size_t, [c_int, c_int64, c_int64, c_int64]),
+    "prl_qk_norm_rope_fwd": (
+        c_int,
+        [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int,
+         c_int64, c_int64, c_int64, c_float, c_void_p],
+    ),
+    "prl_qk_norm_rope_bwd": (
+        c_int,
+        [c_void_p, POINTER(c_int64), c_void_p, POINTER(c_int64), c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+         c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_int, c_int64, c_int64,
+         c_int64, c_void_p],
+    ),
     "prl_rope_supported": (c_int, [c_int, c_int64]),
     "prl_rope": (
         c_int,

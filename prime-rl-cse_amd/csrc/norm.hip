@@ -441,6 +441,258 @@ extern "C" int prl_rope(const void* q, void* q_out, const int64_t* q_strides, in
   return PRL_OK;
 }
 
+// ---------------------------------------------------------------- query / key RMSNorm + rotary embedding
+//
+// What a Qwen3 attention block does between its q/k/v projection and the attention itself: RMSNorm over
+// every head of the query and of the key (head dimension 128), then the rotary embedding of both.  As
+// separate launches that is two norms and one rotation forward, and the rotation, two norm backwards, two
+// column-sum finishes and a concatenation of the three projection gradients backward.  Here one launch reads
+// the query and key blocks out of the stacked projection output [token][q heads | k heads | v heads][128] and
+// writes the rotated query and key; the backward reads their gradients and writes the gradient with respect to
+// the projection output straight INTO the stacked gradient matrix, so the projection's backward is one product
+// without a concatenation.  Same switch in the reference as the other block kernels
+// (`model.impl = "liger_kernel"`, src/prime_rl/trainer/model.py:74-75).
+namespace prl {
+
+constexpr int kQkD = 128;
+
+// A row is one (token, head); lanes of a row: each owns one 16-byte vector of the first half of the head
+// dimension and the matching one of the second half (the rotation pairs element i with i + 64).
+template <int DT>
+__global__ __launch_bounds__(256) void k_qk_norm_rope_fwd(const char* __restrict__ y, int64_t y_pitch,
+                                                          const char* __restrict__ wq, const char* __restrict__ wk,
+                                                          const char* __restrict__ cs, const char* __restrict__ sn,
+                                                          int64_t ct, char* __restrict__ q_out,
+                                                          char* __restrict__ k_out, float* __restrict__ rstd,
+                                                          int64_t T, int Hq, int Hk, float eps) {
+  constexpr int ES = DT == PRL_F32 ? 4 : 2;
+  constexpr int VE = 16 / ES;
+  constexpr int LPR = kQkD / (2 * VE);
+  constexpr int RPB = 256 / LPR;
+  const int li = threadIdx.x % LPR, slot = threadIdx.x / LPR;
+  const int H = Hq + Hk;
+  const int64_t rows = T * H;
+  float wq1[VE], wq2[VE], wk1[VE], wk2[VE];
+  load_vec<DT>(wq, li, wq1), load_vec<DT>(wq, li + LPR, wq2);
+  load_vec<DT>(wk, li, wk1), load_vec<DT>(wk, li + LPR, wk2);
+  for (int64_t r = (int64_t)blockIdx.x * RPB + slot; r < rows; r += (int64_t)gridDim.x * RPB) {
+    const int64_t t = r / H;
+    const int hh = (int)(r - t * H);
+    const bool is_q = hh < Hq;
+    const char* xp = y + t * y_pitch + (int64_t)hh * kQkD * ES;
+    char* op = is_q ? q_out + (t * Hq + hh) * kQkD * ES : k_out + (t * Hk + (hh - Hq)) * kQkD * ES;
+    float x1[VE], x2[VE], c1[VE], c2[VE], s1[VE], s2[VE], o1[VE], o2[VE];
+    load_vec<DT>(xp, li, x1), load_vec<DT>(xp, li + LPR, x2);
+    load_vec<DT>(cs + t * ct, li, c1), load_vec<DT>(cs + t * ct, li + LPR, c2);
+    load_vec<DT>(sn + t * ct, li, s1), load_vec<DT>(sn + t * ct, li + LPR, s2);
+    float ss = 0.0f;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) ss = fmaf(x1[e], x1[e], fmaf(x2[e], x2[e], ss));
+    ss = row_sum<LPR>(ss);
+    const float rs = rsqrtf(ss / (float)kQkD + eps);
+    if (li == 0) rstd[r] = rs;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      // the norm's output as the module rounds it (weight * cast(x * rstd), cast again), then the rotation
+      const float n1 = round_to((is_q ? wq1[e] : wk1[e]) * round_to(x1[e] * rs, DT), DT);
+      const float n2 = round_to((is_q ? wq2[e] : wk2[e]) * round_to(x2[e] * rs, DT), DT);
+      o1[e] = fmaf(n1, c1[e], -(n2 * s1[e]));
+      o2[e] = fmaf(n2, c2[e], n1 * s2[e]);
+    }
+    store_unit<DT, VE>(op, li, o1);
+    store_unit<DT, VE>(op, li + LPR, o2);
+  }
+}
+
+// part[blockIdx.x][0..127] = this workgroup's column sums for the query norm's weight, [128..255] the key's
+template <int DT>
+__global__ __launch_bounds__(256) void k_qk_norm_rope_bwd(const char* __restrict__ gq, int64_t gq_ts, int64_t gq_hs,
+                                                          const char* __restrict__ gk, int64_t gk_ts, int64_t gk_hs,
+                                                          const char* __restrict__ y, int64_t y_pitch,
+                                                          const char* __restrict__ wq, const char* __restrict__ wk,
+                                                          const float* __restrict__ rstd,
+                                                          const char* __restrict__ cs, const char* __restrict__ sn,
+                                                          int64_t ct, char* __restrict__ gy, int64_t gy_pitch,
+                                                          float* __restrict__ part, int64_t T, int Hq, int Hk) {
+  constexpr int ES = DT == PRL_F32 ? 4 : 2;
+  constexpr int VE = 16 / ES;
+  constexpr int LPR = kQkD / (2 * VE);
+  constexpr int RPB = 256 / LPR;
+  extern __shared__ float lds[];  // RPB * 256 floats
+  const int li = threadIdx.x % LPR, slot = threadIdx.x / LPR;
+  const int H = Hq + Hk;
+  const int64_t rows = T * H;
+  float wq1[VE], wq2[VE], wk1[VE], wk2[VE];
+  load_vec<DT>(wq, li, wq1), load_vec<DT>(wq, li + LPR, wq2);
+  load_vec<DT>(wk, li, wk1), load_vec<DT>(wk, li + LPR, wk2);
+  float aq1[VE], aq2[VE], ak1[VE], ak2[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) aq1[e] = aq2[e] = ak1[e] = ak2[e] = 0.0f;
+  for (int64_t r = (int64_t)blockIdx.x * RPB + slot; r < rows; r += (int64_t)gridDim.x * RPB) {
+    const int64_t t = r / H;
+    const int hh = (int)(r - t * H);
+    const bool is_q = hh < Hq;
+    const char* gp = is_q ? gq + t * gq_ts + (int64_t)hh * gq_hs : gk + t * gk_ts + (int64_t)(hh - Hq) * gk_hs;
+    const char* xp = y + t * y_pitch + (int64_t)hh * kQkD * ES;
+    char* op = gy + t * gy_pitch + (int64_t)hh * kQkD * ES;
+    float g1[VE], g2[VE], x1[VE], x2[VE], c1[VE], c2[VE], s1[VE], s2[VE], o1[VE], o2[VE];
+    load_vec<DT>(gp, li, g1), load_vec<DT>(gp, li + LPR, g2);
+    load_vec<DT>(xp, li, x1), load_vec<DT>(xp, li + LPR, x2);
+    load_vec<DT>(cs + t * ct, li, c1), load_vec<DT>(cs + t * ct, li + LPR, c2);
+    load_vec<DT>(sn + t * ct, li, s1), load_vec<DT>(sn + t * ct, li + LPR, s2);
+    const float rs = rstd[r];
+    float dot = 0.0f;
+    float n1[VE], n2[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      // the rotation's transpose gives the gradient with respect to the norm's output ...
+      const float d1 = fmaf(g1[e], c1[e], g2[e] * s2[e]);
+      const float d2 = fmaf(g2[e], c2[e], -(g1[e] * s1[e]));
+      // ... and the norm's backward follows: xh = x rstd, gx = rstd (d w - xh mean(d w xh))
+      x1[e] *= rs, x2[e] *= rs;
+      if (is_q) {
+        aq1[e] = fmaf(d1, round_to(x1[e], DT), aq1[e]), aq2[e] = fmaf(d2, round_to(x2[e], DT), aq2[e]);
+      } else {
+        ak1[e] = fmaf(d1, round_to(x1[e], DT), ak1[e]), ak2[e] = fmaf(d2, round_to(x2[e], DT), ak2[e]);
+      }
+      n1[e] = d1 * (is_q ? wq1[e] : wk1[e]);
+      n2[e] = d2 * (is_q ? wq2[e] : wk2[e]);
+      dot = fmaf(n1[e], x1[e], fmaf(n2[e], x2[e], dot));
+    }
+    dot = row_sum<LPR>(dot) * (1.0f / (float)kQkD);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      o1[e] = rs * (n1[e] - x1[e] * dot);
+      o2[e] = rs * (n2[e] - x2[e] * dot);
+    }
+    store_unit<DT, VE>(op, li, o1);
+    store_unit<DT, VE>(op, li + LPR, o2);
+  }
+#pragma unroll
+  for (int e = 0; e < VE; ++e) {
+    float* row = lds + slot * 2 * kQkD;
+    row[li * VE + e] = aq1[e], row[kQkD / 2 + li * VE + e] = aq2[e];
+    row[kQkD + li * VE + e] = ak1[e], row[kQkD + kQkD / 2 + li * VE + e] = ak2[e];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * kQkD; c += 256) {
+    float sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < RPB; ++k) sum += lds[k * 2 * kQkD + c];
+    part[(int64_t)blockIdx.x * 2 * kQkD + c] = sum;
+  }
+}
+
+static int qk_blocks(int64_t rows, int dtype) {
+  const int rpb = 256 / (kQkD / (2 * (dtype == PRL_F32 ? 4 : 8)));
+  const int64_t want = (rows + rpb - 1) / rpb;
+  int64_t cap = want / 8;  // at least 8 row steps per workgroup, between 256 and 1024 workgroups
+  if (cap < 256) cap = 256;
+  if (cap > 1024) cap = 1024;
+  return (int)(want < cap ? (want > 0 ? want : 1) : cap);
+}
+
+}  // namespace prl
+
+extern "C" int prl_qk_norm_rope_supported(int dtype, int64_t head_dim) {
+  return (dtype == PRL_F32 || dtype == PRL_BF16) && head_dim == prl::kQkD;
+}
+
+extern "C" size_t prl_qk_norm_rope_bwd_workspace_bytes(int dtype, int64_t T, int64_t q_heads, int64_t k_heads) {
+  return (size_t)prl::qk_blocks(T * (q_heads + k_heads), dtype) * 2 * prl::kQkD * sizeof(float);
+}
+
+static int qk_check(const char* who, int dtype, int64_t T, int64_t Hq, int64_t Hk, int64_t pitch, int64_t ct) {
+  PRL_REQUIRE(dtype == PRL_F32 || dtype == PRL_BF16, "%s: unsupported dtype %d", who, dtype);
+  PRL_REQUIRE(T >= 0 && Hq >= 1 && Hk >= 1 && Hq + Hk <= 4096, "%s: bad sizes", who);
+  const int es = dtype == PRL_F32 ? 4 : 2;
+  PRL_REQUIRE(pitch >= (Hq + Hk) * prl::kQkD && (pitch * es) % 16 == 0 && ct >= prl::kQkD && (ct * es) % 16 == 0,
+              "%s: row pitches must cover the rows and be 16-byte aligned", who);
+  return PRL_OK;
+}
+
+extern "C" int prl_qk_norm_rope_fwd(const void* y, int64_t y_pitch, const void* wq, const void* wk, const void* cos_,
+                                    const void* sin_, int64_t cs_token_stride, void* q_out, void* k_out, float* rstd,
+                                    int dtype, int64_t T, int64_t q_heads, int64_t k_heads, float eps, void* stream) {
+  prl::clear_error();
+  int rc = qk_check("qk_norm_rope_fwd", dtype, T, q_heads, k_heads, y_pitch, cs_token_stride);
+  if (rc != PRL_OK || T == 0) return rc;
+  PRL_REQUIRE(y && wq && wk && cos_ && sin_ && q_out && k_out && rstd, "qk_norm_rope_fwd: NULL argument");
+  PRL_REQUIRE(((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(wq) | reinterpret_cast<uintptr_t>(wk) |
+                reinterpret_cast<uintptr_t>(cos_) | reinterpret_cast<uintptr_t>(sin_) |
+                reinterpret_cast<uintptr_t>(q_out) | reinterpret_cast<uintptr_t>(k_out)) & 15) == 0,
+              "qk_norm_rope_fwd: tensors must be 16-byte aligned");
+  const int es = dtype == PRL_F32 ? 4 : 2;
+  const dim3 grid((unsigned)prl::qk_blocks(T * (q_heads + k_heads), dtype) * 4 > 1024
+                      ? 1024u
+                      : (unsigned)prl::qk_blocks(T * (q_heads + k_heads), dtype) * 4),
+      block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == PRL_BF16)
+    hipLaunchKernelGGL((prl::k_qk_norm_rope_fwd<PRL_BF16>), grid, block, 0, st, (const char*)y, y_pitch * es,
+                       (const char*)wq, (const char*)wk, (const char*)cos_, (const char*)sin_, cs_token_stride * es,
+                       (char*)q_out, (char*)k_out, rstd, T, (int)q_heads, (int)k_heads, eps);
+  else
+    hipLaunchKernelGGL((prl::k_qk_norm_rope_fwd<PRL_F32>), grid, block, 0, st, (const char*)y, y_pitch * es,
+                       (const char*)wq, (const char*)wk, (const char*)cos_, (const char*)sin_, cs_token_stride * es,
+                       (char*)q_out, (char*)k_out, rstd, T, (int)q_heads, (int)k_heads, eps);
+  PRL_CHECK_LAUNCH("qk_norm_rope_fwd");
+  return PRL_OK;
+}
+
+extern "C" int prl_qk_norm_rope_bwd(const void* gq, const int64_t* gq_strides, const void* gk,
+                                    const int64_t* gk_strides, const void* y, int64_t y_pitch, const void* wq,
+                                    const void* wk, const float* rstd, const void* cos_, const void* sin_,
+                                    int64_t cs_token_stride, void* gy, int64_t gy_pitch, void* gw, void* workspace,
+                                    size_t workspace_bytes, int dtype, int64_t T, int64_t q_heads, int64_t k_heads,
+                                    void* stream) {
+  prl::clear_error();
+  int rc = qk_check("qk_norm_rope_bwd", dtype, T, q_heads, k_heads, y_pitch, cs_token_stride);
+  if (rc != PRL_OK) return rc;
+  rc = qk_check("qk_norm_rope_bwd", dtype, T, q_heads, k_heads, gy_pitch, cs_token_stride);
+  if (rc != PRL_OK) return rc;
+  PRL_REQUIRE(gq && gk && gq_strides && gk_strides && y && wq && wk && rstd && cos_ && sin_ && gy && gw,
+              "qk_norm_rope_bwd: NULL argument");
+  const int es = dtype == PRL_F32 ? 4 : 2;
+  PRL_REQUIRE(((reinterpret_cast<uintptr_t>(gq) | reinterpret_cast<uintptr_t>(gk) | reinterpret_cast<uintptr_t>(y) |
+                reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(wq) | reinterpret_cast<uintptr_t>(wk) |
+                reinterpret_cast<uintptr_t>(cos_) | reinterpret_cast<uintptr_t>(sin_) |
+                (uintptr_t)(gq_strides[0] * es) | (uintptr_t)(gq_strides[1] * es) | (uintptr_t)(gk_strides[0] * es) |
+                (uintptr_t)(gk_strides[1] * es)) & 15) == 0,
+              "qk_norm_rope_bwd: tensors and strides must be 16-byte aligned");
+  const int nblk = prl::qk_blocks(T * (q_heads + k_heads), dtype);
+  PRL_REQUIRE(workspace && workspace_bytes >= (size_t)nblk * 2 * prl::kQkD * sizeof(float),
+              "qk_norm_rope_bwd: workspace too small (prl_qk_norm_rope_bwd_workspace_bytes)");
+  hipStream_t st = (hipStream_t)stream;
+  float* part = static_cast<float*>(workspace);
+  const int rpb = 256 / (prl::kQkD / (2 * (16 / es)));
+  const size_t lds = (size_t)rpb * 2 * prl::kQkD * sizeof(float);
+  if (T > 0) {
+    if (dtype == PRL_BF16)
+      hipLaunchKernelGGL((prl::k_qk_norm_rope_bwd<PRL_BF16>), dim3((unsigned)nblk), dim3(256), lds, st, (const char*)gq,
+                         gq_strides[0] * es, gq_strides[1] * es, (const char*)gk, gk_strides[0] * es,
+                         gk_strides[1] * es, (const char*)y, y_pitch * es, (const char*)wq, (const char*)wk, rstd,
+                         (const char*)cos_, (const char*)sin_, cs_token_stride * es, (char*)gy, gy_pitch * es, part, T,
+                         (int)q_heads, (int)k_heads);
+    else
+      hipLaunchKernelGGL((prl::k_qk_norm_rope_bwd<PRL_F32>), dim3((unsigned)nblk), dim3(256), lds, st, (const char*)gq,
+                         gq_strides[0] * es, gq_strides[1] * es, (const char*)gk, gk_strides[0] * es,
+                         gk_strides[1] * es, (const char*)y, y_pitch * es, (const char*)wq, (const char*)wk, rstd,
+                         (const char*)cos_, (const char*)sin_, cs_token_stride * es, (char*)gy, gy_pitch * es, part, T,
+                         (int)q_heads, (int)k_heads);
+    PRL_CHECK_LAUNCH("qk_norm_rope_bwd");
+  }
+  const dim3 fgrid((unsigned)(2 * prl::kQkD / 32));
+  if (dtype == PRL_BF16)
+    hipLaunchKernelGGL((prl::k_colsum_finish<PRL_BF16>), fgrid, dim3(1024), 0, st, part, T > 0 ? nblk : 0,
+                       2 * prl::kQkD, (char*)gw);
+  else
+    hipLaunchKernelGGL((prl::k_colsum_finish<PRL_F32>), fgrid, dim3(1024), 0, st, part, T > 0 ? nblk : 0,
+                       2 * prl::kQkD, (char*)gw);
+  PRL_CHECK_LAUNCH("qk_norm_rope_bwd(finish)");
+  return PRL_OK;
+}
+
 // ---------------------------------------------------------------- SwiGLU
 //
 // out = silu(gate) * up, and its backward, element-wise over contiguous tensors (the gated MLP of the

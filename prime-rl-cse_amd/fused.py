@@ -353,6 +353,102 @@ def _fused_rmsnorm_forward(self: nn.Module, hidden_states: Tensor) -> Tensor:
     return self._prl_torch_forward(hidden_states)
 
 
+class _QKVNormRope(torch.autograd.Function):
+    """Everything a Qwen3 attention block does between its input and its attention call, for one packed row:
+    ONE product over the stacked q/k/v weights, one kernel for the query / key RMSNorm and the rotary embedding;
+    backward: one kernel that writes the query and key gradients into the stacked gradient matrix, the value
+    gradient copied beside them, ONE product each for dx and the stacked dW."""
+
+    @staticmethod
+    def forward(ctx, x, stacked, wq, wk, wv, nq, nk, cos, sin, eps: float):
+        dev = x.device
+        lib = C.load()
+        x2 = _rows2d(x)
+        t, d = x2.shape[0], 128
+        hq, hk = wq.shape[0] // d, wk.shape[0] // d
+        y = x2 @ stacked.t()
+        q = torch.empty((t, hq, d), dtype=x.dtype, device=dev)
+        k = torch.empty((t, hk, d), dtype=x.dtype, device=dev)
+        rstd = torch.empty((t, hq + hk), dtype=torch.float32, device=dev)
+        cos2, sin2 = cos.reshape(t, d), sin.reshape(t, d)
+        with C.on_device(dev), C.timed("prl_qk_norm_rope_fwd", dev):
+            C.check(lib.prl_qk_norm_rope_fwd(C.ptr(y), y.stride(0), C.ptr(nq), C.ptr(nk), C.ptr(cos2), C.ptr(sin2),
+                                             cos2.stride(0), C.ptr(q), C.ptr(k), C.ptr(rstd), C.dtype_code(x), t, hq,
+                                             hk, eps, C.stream_ptr(dev)), "prl_qk_norm_rope_fwd")
+        ctx.save_for_backward(x2, stacked, y, rstd, nq, nk, cos2, sin2)
+        ctx.lead, ctx.heads = x.shape[:-1], (hq, hk)
+        ctx.sizes = [wq.shape[0], wk.shape[0], wv.shape[0]]
+        v = y[:, wq.shape[0] + wk.shape[0]:]
+        # [1, heads, T, d] views, the layout the attention functions take
+        return (q.view(1, t, hq, d).transpose(1, 2), k.view(1, t, hk, d).transpose(1, 2),
+                v.view(1, t, -1, d).transpose(1, 2))
+
+    @staticmethod
+    def backward(ctx, gq, gk, gv):
+        x2, stacked, y, rstd, nq, nk, cos2, sin2 = ctx.saved_tensors
+        dev = x2.device
+        lib = C.load()
+        t, d = x2.shape[0], 128
+        hq, hk = ctx.heads
+        nqk = ctx.sizes[0] + ctx.sizes[1]
+        gy = torch.empty_like(y)
+        gw = torch.empty(2 * d, dtype=y.dtype, device=dev)
+
+        def rows(g: Tensor, h: int) -> Tensor:  # [1, h, T, d] -> [T, h, d] with 16-byte aligned strides
+            g = g.transpose(1, 2).reshape(t, h, d)
+            es = g.element_size()
+            if g.stride(2) != 1 or (g.stride(0) * es) % 16 or (g.stride(1) * es) % 16 or g.data_ptr() % 16:
+                g = g.contiguous()
+            return g
+
+        gq3 = rows(gq, hq) if gq is not None else torch.zeros((t, hq, d), dtype=y.dtype, device=dev)
+        gk3 = rows(gk, hk) if gk is not None else torch.zeros((t, hk, d), dtype=y.dtype, device=dev)
+        code = C.dtype_code(y)
+        ws_bytes = lib.prl_qk_norm_rope_bwd_workspace_bytes(code, t, hq, hk)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        s2 = lambda g: (C.c_int64 * 2)(g.stride(0), g.stride(1))
+        with C.on_device(dev), C.timed("prl_qk_norm_rope_bwd", dev):
+            C.check(lib.prl_qk_norm_rope_bwd(C.ptr(gq3), s2(gq3), C.ptr(gk3), s2(gk3), C.ptr(y), y.stride(0), C.ptr(nq),
+                                             C.ptr(nk), C.ptr(rstd), C.ptr(cos2), C.ptr(sin2), cos2.stride(0),
+                                             C.ptr(gy), gy.stride(0), C.ptr(gw), C.ptr(ws), ws_bytes, code, t, hq, hk,
+                                             C.stream_ptr(dev)), "prl_qk_norm_rope_bwd")
+        if gv is not None:
+            gy[:, nqk:].copy_(gv.transpose(1, 2).reshape(t, ctx.sizes[2]))
+        else:
+            gy[:, nqk:].zero_()
+        dx = (gy @ stacked).view(*ctx.lead, x2.shape[1]) if ctx.needs_input_grad[0] else None
+        dw = (gy.t() @ x2).split(ctx.sizes, dim=0)
+        return dx, None, dw[0], dw[1], dw[2], gw[:d], gw[d:], None, None, None
+
+
+def _fused_attention_forward(self: nn.Module, hidden_states: Tensor, position_embeddings: Any,
+                             attention_mask: Tensor | None, past_key_values: Any = None, **kwargs: Any):
+    """The forward of a transformers Qwen3-style attention block with the steps before the attention call taken
+    by `_QKVNormRope` when they qualify (one packed row, stacked q/k/v weights, head dimension 128, per-head
+    query / key norms); anything else goes to the block's own forward."""
+    x = hidden_states
+    cos, sin = position_embeddings
+    qn, kn = getattr(self, "q_norm", None), getattr(self, "k_norm", None)
+    ok = past_key_values is None and x.ndim == 3 and x.shape[0] == 1 and self.head_dim == 128 \
+        and qn is not None and kn is not None and hasattr(qn, "variance_epsilon") \
+        and qn.variance_epsilon == kn.variance_epsilon and not hasattr(qn.weight, "to_local") \
+        and cos.dtype == x.dtype and cos.shape == (1, x.shape[1], 128) and cos.stride(-1) == 1 \
+        and sin.stride() == cos.stride() and not cos.requires_grad \
+        and (cos.stride(1) * cos.element_size()) % 16 == 0 and cos.data_ptr() % 16 == 0 and sin.data_ptr() % 16 == 0
+    stacked = _stackable(x, self.q_proj, self.k_proj, self.v_proj) if ok else None
+    if stacked is None or not C.load().prl_qk_norm_rope_supported(C.dtype_code(x), self.head_dim):
+        return self._prl_torch_forward(hidden_states, position_embeddings, attention_mask, past_key_values, **kwargs)
+    q, k, v = _QKVNormRope.apply(x, stacked, self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, qn.weight,
+                                 kn.weight, cos, sin, float(qn.variance_epsilon))
+    from transformers.modeling_utils import ALL_ATTENTION_FUNCTIONS
+
+    attend = ALL_ATTENTION_FUNCTIONS[self.config._attn_implementation]  # what the block's own forward looks up
+    out, weights = attend(self, q, k, v, attention_mask, dropout=0.0 if not self.training else self.attention_dropout,
+                          scaling=self.scaling, sliding_window=getattr(self, "sliding_window", None), **kwargs)
+    out = out.reshape(*x.shape[:-1], -1).contiguous()
+    return self.o_proj(out), weights
+
+
 class _QKVShare:
     """What the three projections of one attention module share: the query projection, called first, runs the
     stacked product and leaves the key and value pieces for the two calls that follow on the same input."""
@@ -429,6 +525,10 @@ def fuse_model(model: nn.Module) -> dict[str, int]:
                 m._prl_qkv = share
                 m.forward = types.MethodType(fn, m)
             done["qkv"] += 1
+            if hasattr(module, "q_norm") and hasattr(module, "k_norm") and hasattr(module, "head_dim") \
+                    and hasattr(module, "o_proj") and not hasattr(module, "_prl_torch_forward"):
+                module._prl_torch_forward = module.forward
+                module.forward = types.MethodType(_fused_attention_forward, module)
     return done
 
 

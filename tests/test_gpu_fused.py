@@ -309,13 +309,13 @@ def test_stacked_products_over_adjacent_weights_match_the_separate_ones(dtype):
     pos = torch.cat([torch.arange(n) for n in lengths])[None]
     plan = attention.plan_from_position_ids(pos, DEV)
     calls = []
-    real = fused._LinearSplit.apply
+    real = fused._QKVNormRope.apply
     try:
-        fused._LinearSplit.apply = staticmethod(lambda *a: (calls.append(1), real(*a))[1])
+        fused._QKVNormRope.apply = staticmethod(lambda *a: (calls.append(1), real(*a))[1])
         got = T.forward(stacked, ids, pos.to(DEV), plan)
     finally:
-        fused._LinearSplit.apply = real
-    assert len(calls) == 2  # one stacked q/k/v product per layer
+        fused._QKVNormRope.apply = real
+    assert len(calls) == 2  # per layer: one stacked q/k/v product, then query / key norm + rotary in one kernel
     want = T.forward(plain, ids, pos.to(DEV), plan)
     got.float().square().mean().backward()
     want.float().square().mean().backward()
@@ -326,3 +326,52 @@ def test_stacked_products_over_adjacent_weights_match_the_separate_ones(dtype):
         assert b.grad is not None and b.grad.shape == a.grad.shape, name
         assert (b.grad.float() - a.grad.float()).norm().item() <= tol * a.grad.float().norm().item() + 1e-9, name
     fused.unfuse_model(stacked)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_qk_norm_rope_function_against_the_separate_steps(dtype):
+    """`_QKVNormRope` against projection, per-head RMSNorm and rotary embedding spelled out in torch (float64 for
+    the fp32 case), outputs and every gradient; a ragged head split (12 query heads, 4 key / value heads)."""
+    from prime_rl_cse_amd.fused import _QKVNormRope
+
+    t, hid, hq, hk, d = 77, 256, 12, 4, 128
+    gen = torch.Generator().manual_seed(8)
+    ref_dtype = torch.float64 if dtype == torch.float32 else torch.float32
+    x = torch.randn(1, t, hid, generator=gen)
+    flat = torch.randn((hq + 2 * hk) * d, hid, generator=gen) * hid ** -0.5
+    nq, nk = 1.0 + 0.1 * torch.randn(d, generator=gen), 1.0 + 0.1 * torch.randn(d, generator=gen)
+    ang = torch.rand(1, t, d // 2, generator=gen) * 6.28
+    cos, sin = torch.cat([ang.cos(), ang.cos()], -1), torch.cat([ang.sin(), ang.sin()], -1)
+    gq, gk, gv = (torch.randn(1, h, t, d, generator=gen) for h in (hq, hk, hk))
+
+    def run(fused_path: bool):
+        dt = dtype if fused_path else ref_dtype
+        xs = x.to(DEV).to(dtype).to(dt).requires_grad_(True)
+        w = flat.to(DEV).to(dtype).to(dt)  # one storage: the three weights are adjacent rows of it
+        wq, wk, wv = (p.detach().requires_grad_(True) for p in w.split([hq * d, hk * d, hk * d]))
+        a, b = nq.to(DEV).to(dtype).to(dt).requires_grad_(True), nk.to(DEV).to(dtype).to(dt).requires_grad_(True)
+        c, s_ = cos.to(DEV).to(dtype).to(dt), sin.to(DEV).to(dtype).to(dt)
+        if fused_path:
+            stacked = fused.adjacent_rows(wq, wk, wv)
+            assert stacked is not None and stacked.shape == w.shape
+            q, k, v = _QKVNormRope.apply(xs, stacked, wq, wk, wv, a, b, c, s_, 1e-6)
+        else:
+            def norm(z, weight):
+                return weight * (z * torch.rsqrt(z.pow(2).mean(-1, keepdim=True) + 1e-6))
+
+            def rot(z):
+                return torch.cat([-z[..., d // 2:], z[..., : d // 2]], -1)
+
+            q = norm((xs @ wq.t()).view(1, t, hq, d), a).transpose(1, 2)
+            k = norm((xs @ wk.t()).view(1, t, hk, d), b).transpose(1, 2)
+            v = (xs @ wv.t()).view(1, t, hk, d).transpose(1, 2)
+            q, k = q * c[:, None] + rot(q) * s_[:, None], k * c[:, None] + rot(k) * s_[:, None]
+        loss = (q * gq.to(DEV).to(dt)).sum() + (k * gk.to(DEV).to(dt)).sum() + (v * gv.to(DEV).to(dt)).sum()
+        loss.backward()
+        return [z.detach().double() for z in (q, k, v, xs.grad, wq.grad, wk.grad, wv.grad, a.grad, b.grad)]
+
+    got, want = run(True), run(False)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    for name, g, w in zip("q k v dx dwq dwk dwv dnq dnk".split(), got, want):
+        assert g.shape == w.shape, name
+        assert (g - w).norm().item() <= tol * w.norm().item() + 1e-9, (name, (g - w).norm().item(), w.norm().item())
