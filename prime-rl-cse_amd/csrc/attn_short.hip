@@ -54,14 +54,24 @@ __device__ __forceinline__ bf16x8 acc_frag(const f32x16& x, int s) {
 // row of an accumulator tile that register i of lane half h holds
 __device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
-// rows [0, len) of one head, tokens start .. start+len-1, into a natural [token][d] image; other rows zero
+// rows [0, len) of one head, tokens start .. start+len-1, into a natural [token][d] image; other rows zero.
+// Rows past the end are read from the sample's last row and zeroed by a select, not skipped by a branch: a
+// branch per load makes the compiler wait for every load before it issues the next (one memory round trip
+// per 16 bytes); this way all of a thread's loads are in flight together.  Needs len >= 1.
 __device__ __forceinline__ void stage_rows(uint16_t* img, const AttnView& x, int64_t start, int len, int head) {
+  constexpr int kIt = kAL * kAD / 8 / kAThreads;
+  u32x4 v[kIt];
 #pragma unroll
-  for (int it = 0; it < kAL * kAD / 8 / kAThreads; ++it) {
+  for (int it = 0; it < kIt; ++it) {
     const int id = it * kAThreads + threadIdx.x, tok = id >> 4, ch = id & 15;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (tok < len) v = *reinterpret_cast<const u32x4*>(x.p + (start + tok) * x.ts + head * x.hs + ch * 8);
-    *reinterpret_cast<u32x4*>(img + tok * kAP + ch * 8) = v;
+    const int src = tok < len ? tok : len - 1;
+    v[it] = *reinterpret_cast<const u32x4*>(x.p + (start + src) * x.ts + head * x.hs + ch * 8);
+  }
+#pragma unroll
+  for (int it = 0; it < kIt; ++it) {
+    const int id = it * kAThreads + threadIdx.x, tok = id >> 4, ch = id & 15;
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    *reinterpret_cast<u32x4*>(img + tok * kAP + ch * 8) = tok < len ? v[it] : zero;
   }
 }
 // fragment of a natural image for a product that sums over d: row `row`, d = 16 kk + 8 h .. + 7
@@ -86,12 +96,14 @@ __device__ __forceinline__ bf16x8 frag_cols(const uint16_t* img, int d0, int tok
   const s16x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
   return __builtin_bit_cast(bf16x8, v);
 }
-// the same fragment of a row read from global memory (token `tok` of the sample, or zeros past its end)
+// the same fragment of a row read from global memory (token `tok` of the sample, or zeros past its end; read
+// without a branch, as in stage_rows; needs len >= 1)
 __device__ __forceinline__ bf16x8 frag_global(const AttnView& x, int64_t start, int len, int head, int tok, int kk,
                                               int h) {
-  u32x4 v = {0u, 0u, 0u, 0u};
-  if (tok < len) v = *reinterpret_cast<const u32x4*>(x.p + (start + tok) * x.ts + head * x.hs + 16 * kk + 8 * h);
-  return as_frag(v);
+  const int src = tok < len ? tok : len - 1;
+  const u32x4 v = *reinterpret_cast<const u32x4*>(x.p + (start + src) * x.ts + head * x.hs + 16 * kk + 8 * h);
+  const u32x4 zero = {0u, 0u, 0u, 0u};
+  return as_frag(tok < len ? v : zero);
 }
 
 __device__ __forceinline__ void sample_range(const int32_t* cu, int s, int64_t T, int64_t& start, int& len) {
@@ -116,6 +128,7 @@ __global__ __launch_bounds__(kAThreads) void k_attn_short_fwd(AttnView q, AttnVi
   int64_t start;
   int len;
   sample_range(cu, s, T, start, len);
+  if (len == 0) return;  // the whole workgroup, before any barrier
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int query = 32 * w + r;
   bf16x8 qf[8];
@@ -204,6 +217,7 @@ __global__ __launch_bounds__(kAThreads) void k_attn_short_bwd_dq(AttnView q, Att
   int64_t start;
   int len;
   sample_range(cu, s, T, start, len);
+  if (len == 0) return;  // the whole workgroup, before any barrier
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int query = 32 * w + r;
   bf16x8 qf[8], dof[8];
@@ -288,6 +302,7 @@ __global__ __launch_bounds__(kAThreads) void k_attn_short_bwd_dkv(AttnView q, At
   int64_t start;
   int len;
   sample_range(cu, s, T, start, len);
+  if (len == 0) return;  // the whole workgroup, before any barrier
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int key = 32 * w + r;
   bf16x8 kf[8], vf[8];
