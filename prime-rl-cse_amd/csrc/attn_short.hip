@@ -54,24 +54,32 @@ __device__ __forceinline__ bf16x8 acc_frag(const f32x16& x, int s) {
 // row of an accumulator tile that register i of lane half h holds
 __device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
-// rows [0, len) of one head, tokens start .. start+len-1, into a natural [token][d] image; other rows zero.
+// rows [0, len) of one head each, tokens start .. start+len-1, into N natural [token][d] images; other rows zero.
 // Rows past the end are read from the sample's last row and zeroed by a select, not skipped by a branch: a
 // branch per load makes the compiler wait for every load before it issues the next (one memory round trip
 // per 16 bytes); this way all of a thread's loads are in flight together.  Needs len >= 1.
-__device__ __forceinline__ void stage_rows(uint16_t* img, const AttnView& x, int64_t start, int len, int head) {
+template <int N>
+__device__ __forceinline__ void stage_images(uint16_t* const (&img)[N], const AttnView* const (&x)[N], int64_t start,
+                                             int len, const int (&head)[N]) {
   constexpr int kIt = kAL * kAD / 8 / kAThreads;
-  u32x4 v[kIt];
+  u32x4 v[N][kIt];
 #pragma unroll
-  for (int it = 0; it < kIt; ++it) {
-    const int id = it * kAThreads + threadIdx.x, tok = id >> 4, ch = id & 15;
-    const int src = tok < len ? tok : len - 1;
-    v[it] = *reinterpret_cast<const u32x4*>(x.p + (start + src) * x.ts + head * x.hs + ch * 8);
+  for (int n = 0; n < N; ++n) {
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+      const int id = it * kAThreads + threadIdx.x, tok = id >> 4, ch = id & 15;
+      const int src = tok < len ? tok : len - 1;
+      v[n][it] = *reinterpret_cast<const u32x4*>(x[n]->p + (start + src) * x[n]->ts + head[n] * x[n]->hs + ch * 8);
+    }
   }
 #pragma unroll
-  for (int it = 0; it < kIt; ++it) {
-    const int id = it * kAThreads + threadIdx.x, tok = id >> 4, ch = id & 15;
-    const u32x4 zero = {0u, 0u, 0u, 0u};
-    *reinterpret_cast<u32x4*>(img + tok * kAP + ch * 8) = tok < len ? v[it] : zero;
+  for (int n = 0; n < N; ++n) {
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+      const int id = it * kAThreads + threadIdx.x, tok = id >> 4, ch = id & 15;
+      const u32x4 zero = {0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4*>(img[n] + tok * kAP + ch * 8) = tok < len ? v[n][it] : zero;
+    }
   }
 }
 // fragment of a natural image for a product that sums over d: row `row`, d = 16 kk + 8 h .. + 7
@@ -97,7 +105,7 @@ __device__ __forceinline__ bf16x8 frag_cols(const uint16_t* img, int d0, int tok
   return __builtin_bit_cast(bf16x8, v);
 }
 // the same fragment of a row read from global memory (token `tok` of the sample, or zeros past its end; read
-// without a branch, as in stage_rows; needs len >= 1)
+// without a branch, as in stage_images; needs len >= 1)
 __device__ __forceinline__ bf16x8 frag_global(const AttnView& x, int64_t start, int len, int head, int tok, int kk,
                                               int h) {
   const int src = tok < len ? tok : len - 1;
@@ -134,8 +142,12 @@ __global__ __launch_bounds__(kAThreads) void k_attn_short_fwd(AttnView q, AttnVi
   bf16x8 qf[8];
 #pragma unroll
   for (int kk = 0; kk < 8; ++kk) qf[kk] = frag_global(q, start, len, hq, query, kk, h);
-  stage_rows(Ks, k, start, len, hkv);
-  stage_rows(Vs, v, start, len, hkv);
+  {
+    uint16_t* const imgs[2] = {Ks, Vs};
+    const AttnView* const views[2] = {&k, &v};
+    const int heads[2] = {hkv, hkv};
+    stage_images<2>(imgs, views, start, len, heads);
+  }
   __syncthreads();
   int ntile = (len + 31) >> 5;
   if (ntile > w + 1) ntile = w + 1;  // causal: no key tile beyond the wave's own queries
@@ -240,8 +252,12 @@ __global__ __launch_bounds__(kAThreads) void k_attn_short_bwd_dq(AttnView q, Att
     ls = lse2[(int64_t)hq * T + start + query];
     if (h == 0) delta[(int64_t)hq * T + start + query] = dl;
   }
-  stage_rows(Ks, k, start, len, hkv);
-  stage_rows(Vs, v, start, len, hkv);
+  {
+    uint16_t* const imgs[2] = {Ks, Vs};
+    const AttnView* const views[2] = {&k, &v};
+    const int heads[2] = {hkv, hkv};
+    stage_images<2>(imgs, views, start, len, heads);
+  }
   __syncthreads();
   int ntile = (len + 31) >> 5;
   if (ntile > w + 1) ntile = w + 1;
@@ -316,10 +332,14 @@ __global__ __launch_bounds__(kAThreads) void k_attn_short_bwd_dkv(AttnView q, At
   for (int g0 = 0; g0 < G; g0 += 2) {
     const int heads = G - g0 < 2 ? G - g0 : 2;
     __syncthreads();  // the previous pair's images are no longer read
+    for (int j = 0; j < 2 * heads; ++j) {  // one image per round of 8 loads: 16 or 32 in flight measured 8 % slower here
+      uint16_t* const imgs[1] = {lds + j * kAImg};
+      const AttnView* const views[1] = {(j & 1) ? &dout : &q};
+      const int hs[1] = {hkv * G + g0 + (j >> 1)};
+      stage_images<1>(imgs, views, start, len, hs);
+    }
     for (int j = 0; j < heads; ++j) {
       const int hq = hkv * G + g0 + j;
-      stage_rows(lds + (2 * j) * kAImg, q, start, len, hq);
-      stage_rows(lds + (2 * j + 1) * kAImg, dout, start, len, hq);
       if (threadIdx.x < kAL) {
         const bool in = (int)threadIdx.x < len;
         row_stats[(2 * j) * kAL + threadIdx.x] = in ? lse2[(int64_t)hq * T + start + threadIdx.x] : 0.0f;
