@@ -435,13 +435,14 @@ def _fused_attention_forward(self: nn.Module, hidden_states: Tensor, position_em
         and cos.dtype == x.dtype and cos.shape == (1, x.shape[1], 128) and cos.stride(-1) == 1 \
         and sin.stride() == cos.stride() and not cos.requires_grad \
         and (cos.stride(1) * cos.element_size()) % 16 == 0 and cos.data_ptr() % 16 == 0 and sin.data_ptr() % 16 == 0
+    from transformers.modeling_utils import ALL_ATTENTION_FUNCTIONS
+
     stacked = _stackable(x, self.q_proj, self.k_proj, self.v_proj) if ok else None
-    if stacked is None or not C.load().prl_qk_norm_rope_supported(C.dtype_code(x), self.head_dim):
+    if stacked is None or self.config._attn_implementation not in ALL_ATTENTION_FUNCTIONS \
+            or not C.load().prl_qk_norm_rope_supported(C.dtype_code(x), self.head_dim):
         return self._prl_torch_forward(hidden_states, position_embeddings, attention_mask, past_key_values, **kwargs)
     q, k, v = _QKVNormRope.apply(x, stacked, self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, qn.weight,
                                  kn.weight, cos, sin, float(qn.variance_epsilon))
-    from transformers.modeling_utils import ALL_ATTENTION_FUNCTIONS
-
     attend = ALL_ATTENTION_FUNCTIONS[self.config._attn_implementation]  # what the block's own forward looks up
     out, weights = attend(self, q, k, v, attention_mask, dropout=0.0 if not self.training else self.attention_dropout,
                           scaling=self.scaling, sliding_window=getattr(self, "sliding_window", None), **kwargs)
