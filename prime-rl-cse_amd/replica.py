@@ -17,7 +17,9 @@ quarter of the time.  So here:
   * a micro-batch (forward, the HIP loss path, backward, gradient accumulation)
     is captured once per input shape in a HIP graph and replayed: one launch
     from the host instead of thousands.  Shapes seen for the first time, and
-    more distinct shapes than `max_graphs`, run eagerly through the same code;
+    more distinct shapes than `max_graphs`, run eagerly through the same code
+    (a graph keeps its activations' memory: ~30 GB for a 16 K-token row of the
+    0.6B model, so `max_graphs` = 4 is sized for 288 GB);
   * a step ends with ONE fp32 reduce-scatter (mean over ranks), the gradient
     norm, the optimizer on the shard and ONE bf16 all-gather: the same traffic
     as FSDP2 with parameters kept gathered, issued outside the graphs.
@@ -283,6 +285,8 @@ class Replica:
                 self._captured[key] = cap
                 while len(self._captured) > self.max_graphs:
                     self._captured.popitem(last=False)
+        if len(self._seen) > 4096:  # rows of ever-changing lengths: forget, rather than remember every shape
+            self._seen.clear()
         self._seen.add(key)
         if cap is not None:
             self._captured.move_to_end(key)
@@ -310,12 +314,10 @@ class Replica:
                    recomputed_errors: list[Tensor] | None = None, join_tokens: int | None = None) -> Any:
         """One optimizer step over this rank's micro-batches (src/prime_rl/trainer/rl/train.py:259-364);
         same results and the same `StepResult` as `trainer.train_step`, micro-batches joined the same way."""
-        from .trainer import MERGE_MAX_TOKENS
+        from .trainer import (MERGE_MAX_TOKENS, StepResult, attention_plan, join_micro_batches, join_per_row,
+                              local_loss_scale, restore_row_starts)
 
         join_tokens = MERGE_MAX_TOKENS if join_tokens is None else join_tokens
-        from .trainer import (StepResult, attention_plan, join_micro_batches, join_per_row, local_loss_scale,
-                              restore_row_starts)
-
         t0 = time.perf_counter()
         inv_scale = 1.0 / max(float(local_loss_scale(micro_batches, loss_config)), 1.0)
         self._scale.fill_(inv_scale)
