@@ -282,8 +282,14 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, micro_batches
     loss_scale = local_loss_scale(micro_batches, loss_config)
     tensors = Tensors()
     tokens = 0
-    rows = join_micro_batches(micro_batches, join_tokens) if loss_config.ratio_type == "token" and join_tokens > 0 \
-        else None
+    # Ranks may end up with different numbers of joined rows (their rows differ in length).  That is harmless when
+    # a step's collectives do not depend on the number of passes (parameters kept gathered: one all-gather with the
+    # first pass, one reduce-scatter with the last); a model that reshards after every pass must run the same
+    # number of passes on every rank, so there the micro-batches stay apart.
+    one_rank = not dist.is_initialized() or dist.get_world_size() == 1
+    passes_are_local = one_rank or getattr(model, "_prl_keep_gathered", False) or not hasattr(model, "unshard")
+    rows = join_micro_batches(micro_batches, join_tokens) \
+        if loss_config.ratio_type == "token" and join_tokens > 0 and passes_are_local else None
     units = [r.micro_batch for r in rows] if rows is not None else micro_batches
     if rows is not None and recomputed_errors is not None:
         recomputed_errors = join_per_row(recomputed_errors, rows)
