@@ -202,6 +202,41 @@ def test_trainer_entry_point_on_rollout_files(tmp_path, monkeypatch):
     assert (tmp_path / "weights" / "step_2" / "pytorch_model.bin").exists()
 
 
+def test_rollout_files_through_both_trainers_agree(tmp_path, monkeypatch):
+    """Ragged rollouts (prompts masked, completions of many lengths, several rows per step) from
+    `rollouts/step_N/rank_0.pt` through the FSDP2 trainer and through the whole-model trainer with graphs, fused
+    blocks on in both: the same logged numbers step by step."""
+    from prime_rl_cse_amd.settings import RLTrainerConfig
+    from prime_rl_cse_amd.train import train
+
+    gen = torch.Generator().manual_seed(17)
+    for step in range(3):
+        rollouts = []
+        for pid in range(24):
+            p, c = int(torch.randint(3, 30, (1,), generator=gen)), int(torch.randint(1, 90, (1,), generator=gen))
+            rollouts.append(prl.Rollout(pid, torch.randint(0, 1000, (p,), generator=gen).tolist(), [0] * p,
+                                        torch.randint(0, 1000, (c,), generator=gen).tolist(), [1] * c,
+                                        (-11.9 + 0.05 * torch.randn(c, generator=gen)).tolist(), False, 1.0,
+                                        float(torch.randn(1, generator=gen))))
+        batches = prl.prepare_batch(rollouts, 1.0, None, 24, 4, 128, 1)
+        for root in ("fsdp", "graphs"):
+            prl.save_rollout_batches(batches, tmp_path / root, step)
+    runs = {}
+    for name, port in (("fsdp", 29781), ("graphs", 29782)):
+        _single_rank_env(monkeypatch, port)
+        model = {"debug": {"num_layers": 2}, "impl": "liger_kernel"}
+        if name == "graphs":
+            model["compile"] = {}
+        cfg = RLTrainerConfig(max_steps=3, output_dir=tmp_path / name, model=model)
+        runs[name] = train(cfg)
+    assert len(runs["fsdp"]) == len(runs["graphs"]) == 3
+    for a, b in zip(runs["fsdp"], runs["graphs"]):
+        assert a["optim/grad_norm"] > 0
+        for key in ("loss/mean", "loss/max", "entropy/mean", "probs/mean", "importance_ratio/mean",
+                    "importance_ratio/max", "is_clipped/mean", "optim/grad_norm"):
+            assert b[key] == pytest.approx(a[key], rel=2e-2, abs=5e-4 if key.startswith("loss") else 1e-6), key
+
+
 def test_statistics_exchange_runs_over_rccl(monkeypatch):
     """The between-pass all-reduces of `Tensors` (int32 histograms, int64 counts, float64 moments, int32
     extrema with MAX) through the RCCL backend.  One rank is all this box has, so the group has one member and
