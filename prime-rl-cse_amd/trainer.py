@@ -343,22 +343,37 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, micro_batches
 
 @torch.no_grad()
 def recompute_logprobs(logprob_model: nn.Module, micro_batches: list[MicroBatch],
-                       device: torch.device | str = "cuda") -> list[Tensor]:
+                       device: torch.device | str = "cuda", join_tokens: int = MERGE_MAX_TOKENS) -> list[Tensor]:
     """Replace every micro-batch's sampler log-probabilities by the ones
     `logprob_model` assigns (the trainer's optional recompute pass,
     src/prime_rl/trainer/rl/train.py:227-245).  Returns, per micro-batch, the
     device tensor exp(recomputed - sampler) that the trainer logs as
     `recomputed_logprob_error`.  Same single pass over the logits as the training
-    forward; nothing is kept for a backward."""
+    forward; nothing is kept for a backward.  Rows are joined as in `train_step`
+    when the model's forward needs no collective per pass (`join_tokens` = 0 keeps
+    them apart); the first token of every row then gets the -ln V of the
+    all-zero logits the reference scores it against."""
     from .loss import selective_log_softmax, shift_logits
 
-    errors = []
-    for mb in micro_batches:
+    one_rank = not dist.is_initialized() or dist.get_world_size() == 1
+    joinable = join_tokens > 0 and (one_rank or not hasattr(logprob_model, "unshard"))
+    rows = join_micro_batches(micro_batches, join_tokens) if joinable else \
+        [JoinedRows(mb, [0], [int(mb["input_ids"].shape[1])], mb["loss_mask"]) for mb in micro_batches]
+    errors, k = [], 0
+    for r in rows:
+        mb = r.micro_batch
         ids = mb["input_ids"].to(device)
         logits = forward(logprob_model, ids, mb["position_ids"].to(device), attention_plan(mb, device))
         lp = selective_log_softmax(shift_logits(logits) / mb["temperature"], ids)
-        errors.append(torch.exp(lp - mb["logprobs"].to(device)))
-        mb["logprobs"] = lp.cpu()
+        del logits
+        if len(r.starts) > 1:
+            idx = torch.tensor(r.starts[1:], dtype=torch.int64).to(device, non_blocking=True)
+            lp[:, idx] = -float(torch.log(torch.tensor(float(logprob_model.config.vocab_size), dtype=torch.float32)))
+        for a, n in zip(r.starts, r.lengths):  # back to the micro-batches the caller holds
+            piece = lp[:, a : a + n]
+            errors.append(torch.exp(piece - micro_batches[k]["logprobs"].to(device)))
+            micro_batches[k]["logprobs"] = piece.cpu()
+            k += 1
     return errors
 
 
