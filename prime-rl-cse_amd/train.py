@@ -51,6 +51,36 @@ def model_config_of(config: RLTrainerConfig) -> Any:
     raise ValueError(f"model {mc.name!r} is neither a local directory nor one of {sorted(T.MODEL_DIMS)}")
 
 
+def trainer_mode(config: RLTrainerConfig) -> str:
+    """"replica" (the whole model on every GPU with HIP graphs, replica.py), "fsdp" (FSDP2 as the reference sets it
+    up) or "auto" (replica where the model and optimizer allow it, else FSDP2).  A recipe asks for replica with
+    `[model.compile]`, the reference's switch for its tracing compiler, and for FSDP2 by setting
+    `model.reshard_after_forward` (either way: it then cares how FSDP2 treats its parameters); PRL_TRAINER
+    overrides both.  Without any of these: auto."""
+    import os
+
+    env = os.environ.get("PRL_TRAINER", "").lower()
+    if env in ("replica", "fsdp", "auto"):
+        return env
+    if config.model.compile is not None:
+        return "replica"
+    if "reshard_after_forward" in config.model.model_fields_set:
+        return "fsdp"
+    return "auto"
+
+
+def fused_blocks(config: RLTrainerConfig) -> bool:
+    """Whether the transformer blocks run on this package's HIP kernels: when the recipe says
+    `model.impl = "liger_kernel"` (the reference's switch for fused block kernels) and also when it says nothing;
+    an explicit `impl = "hf"`, or PRL_BLOCKS=eager, keeps the transformers modules as they are."""
+    import os
+
+    env = os.environ.get("PRL_BLOCKS", "").lower()
+    if env in ("eager", "fused"):
+        return env == "fused"
+    return config.model.impl == "liger_kernel" or "impl" not in config.model.model_fields_set
+
+
 def build_model(config: RLTrainerConfig, device: torch.device, mesh: Any, dtype: torch.dtype | None = None,
                 for_training: bool = True, shard: bool = True):
     """The model of `config.model` on `device`; `shard=False` leaves it whole (for `replica.Replica`, or as the
@@ -65,7 +95,7 @@ def build_model(config: RLTrainerConfig, device: torch.device, mesh: Any, dtype:
     else:
         model = T.get_model(cfg, device, dtype or DTYPES[mc.optimization_dtype])
         log(f"{mc.name}: no weights on this machine, training from a random initialisation")
-    if mc.impl == "liger_kernel":  # the reference's switch for fused block kernels; here they are HIP kernels
+    if fused_blocks(config):
         from .fused import fuse_model
 
         log(f"fused block kernels: {fuse_model(model)}")
@@ -120,18 +150,17 @@ def train(config: RLTrainerConfig) -> list[dict[str, float]]:
 def _train(config: RLTrainerConfig, world: Any, device: torch.device, mesh: Any) -> list[dict[str, float]]:
     log(f"Starting RL trainer on {world}")
     replica = None
-    if config.model.compile is not None:
-        # the reference's switch for torch.compile; here: the whole model on every GPU, every micro-batch replayed
-        # from a HIP graph (replica.py), for the models and optimizers that allows
+    mode = trainer_mode(config)
+    if mode != "fsdp":
         from .replica import Replica, eligible
 
         reason = eligible(T.get_model(model_config_of(config), "meta"), config.optim.type, config.model.ac is not None)
         if reason is None:
             model, model_cfg = build_model(config, device, mesh, shard=False)
             replica = Replica(model, lambda m: setup_optimizer(config.optim, m, flat=True))
-            log("model.compile: whole model per GPU, micro-batches replayed from HIP graphs")
-        else:
-            log(f"model.compile ignored ({reason}); FSDP2 as usual")
+            log("whole model per GPU, master weights and optimizer state sharded, micro-batches from HIP graphs")
+        elif mode == "replica" or config.model.compile is not None:
+            log(f"whole-model mode not possible ({reason}); FSDP2")
     if replica is None:
         model, model_cfg = build_model(config, device, mesh)
         optimizer = setup_optimizer(config.optim, model)

@@ -159,6 +159,7 @@ def test_trainer_entry_point_with_model_compile_replays_graphs(tmp_path, monkeyp
     runs = {}
     for name, extra, port in (("fsdp", "", 29771), ("graphs", "\n[model.compile]\nfullgraph = false\n", 29772)):
         _single_rank_env(monkeypatch, port)
+        monkeypatch.setenv("PRL_TRAINER", "fsdp" if name == "fsdp" else "")
         toml = tmp_path / f"{name}.toml"
         toml.write_text(base + extra)
         cfg = parse_argv(RLTrainerConfig, ["@", str(toml), "--output-dir", str(tmp_path / name)], use_env=False)
@@ -227,6 +228,8 @@ def test_rollout_files_through_both_trainers_agree(tmp_path, monkeypatch):
         model = {"debug": {"num_layers": 2}, "impl": "liger_kernel"}
         if name == "graphs":
             model["compile"] = {}
+        else:
+            model["reshard_after_forward"] = True  # a recipe that cares about FSDP2's handling gets FSDP2
         cfg = RLTrainerConfig(max_steps=3, output_dir=tmp_path / name, model=model)
         runs[name] = train(cfg)
     assert len(runs["fsdp"]) == len(runs["graphs"]) == 3

@@ -106,3 +106,20 @@ def test_every_reference_rl_trainer_recipe_loads():
     for f in files:
         c = load_config(RLTrainerConfig, f)
         assert c.model.name
+
+
+def test_trainer_mode_and_block_kernels_follow_the_recipe(monkeypatch):
+    from prime_rl_cse_amd.settings import RLTrainerConfig
+    from prime_rl_cse_amd.train import fused_blocks, trainer_mode
+
+    monkeypatch.delenv("PRL_TRAINER", raising=False)
+    monkeypatch.delenv("PRL_BLOCKS", raising=False)
+    plain = RLTrainerConfig()
+    assert trainer_mode(plain) == "auto" and fused_blocks(plain)
+    assert trainer_mode(RLTrainerConfig(model={"compile": {}})) == "replica"
+    assert trainer_mode(RLTrainerConfig(model={"reshard_after_forward": True})) == "fsdp"
+    assert not fused_blocks(RLTrainerConfig(model={"impl": "hf"}))
+    assert fused_blocks(RLTrainerConfig(model={"impl": "liger_kernel"}))
+    monkeypatch.setenv("PRL_TRAINER", "fsdp")
+    monkeypatch.setenv("PRL_BLOCKS", "eager")
+    assert trainer_mode(RLTrainerConfig(model={"compile": {}})) == "fsdp" and not fused_blocks(plain)
