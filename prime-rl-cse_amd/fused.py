@@ -252,6 +252,53 @@ def adjacent_rows(*weights: Tensor) -> Tensor | None:
     return torch.as_strided(w0.detach(), (rows, w0.shape[1]), (w0.shape[1], 1))
 
 
+def weight_grad(gy: Tensor, x: Tensor) -> Tensor:
+    """dW = gy^T x for gy [rows, out], x [rows, in] (both contiguous), in gy's dtype.
+
+    With a long row (16 K tokens) this product has a small output and a long sum: 1024 x 2048 outputs are 128
+    tiles for 256 compute units, and the BLAS library's pick runs at 0.44-0.87 PFLOP/s where the forward products
+    reach 1.2.  Cutting the sum over the tokens into S batched products and adding the S partial results fills
+    the chip: 164 -> 89 us (o), 181 -> 111 us (down), 217 -> 154 us (q/k/v), 244 -> 203 us (gate/up),
+    `tools/gemm_dw_split.py`.  Small outputs keep their partial results in fp32 (no extra rounding); large ones
+    in bf16, where fp32 partials would cost the time back (relative error 2.4e-3 against 1.7e-3 for one
+    product, both from rounding to bf16)."""
+    rows, n_out = gy.shape
+    n_in = x.shape[1]
+    size = n_out * n_in
+    s = 4 if size <= 5_000_000 else 2
+    if rows < 8192 or rows % s or size > 8_000_000 or gy.dtype != torch.bfloat16:
+        return gy.t() @ x
+    a, b = gy.view(s, rows // s, n_out).transpose(1, 2), x.view(s, rows // s, n_in)
+    if size <= 3_200_000:
+        return torch.bmm(a, b, out_dtype=torch.float32).sum(0).to(gy.dtype)
+    return torch.bmm(a, b).sum(0, dtype=torch.float32).to(gy.dtype)
+
+
+class _Linear(torch.autograd.Function):
+    """x W^T without a bias, as nn.Linear computes it; the backward's dW goes through `weight_grad`."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, weight: Tensor):
+        ctx.save_for_backward(x, weight)
+        return torch.nn.functional.linear(x, weight)
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        x, weight = ctx.saved_tensors
+        g2 = _rows2d(gy)
+        dx = (g2 @ weight).view(x.shape) if ctx.needs_input_grad[0] else None
+        dw = weight_grad(g2, _rows2d(x)) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
+def _split_dw_linear_forward(self: nn.Module, x: Tensor) -> Tensor:
+    w = self.weight
+    if self.bias is not None or hasattr(w, "to_local") or not x.is_cuda or x.dtype != w.dtype \
+            or not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)):
+        return self._prl_torch_forward(x)
+    return _Linear.apply(x, w)
+
+
 def _rows2d(x: Tensor) -> Tensor:
     x2 = x.reshape(-1, x.shape[-1])
     return x2 if x2.is_contiguous() else x2.contiguous()
@@ -278,7 +325,7 @@ class _LinearSplit(torch.autograd.Function):
                  for g, n in zip(grads, ctx.sizes)]
         gy = torch.cat(parts, dim=1)
         dx = (gy @ stacked).view(*ctx.lead, x2.shape[1]) if ctx.needs_input_grad[0] else None
-        dw = (gy.t() @ x2).split(ctx.sizes, dim=0)
+        dw = weight_grad(gy, x2).split(ctx.sizes, dim=0)
         return (dx, None) + tuple(dw)
 
 
@@ -317,7 +364,7 @@ class _GateUpSwiGLU(torch.autograd.Function):
                                                  ggu.data_ptr(), ggu.data_ptr() + n * es, 2 * n, C.dtype_code(gu), rows,
                                                  n, C.stream_ptr(dev)), "prl_swiglu_rows_bwd")
         dx = (ggu @ stacked).view(*ctx.lead, x2.shape[1]) if ctx.needs_input_grad[0] else None
-        dw = ggu.t() @ x2
+        dw = weight_grad(ggu, x2)
         return dx, None, dw[:n], dw[n:]
 
 
@@ -417,7 +464,7 @@ class _QKVNormRope(torch.autograd.Function):
         else:
             gy[:, nqk:].zero_()
         dx = (gy @ stacked).view(*ctx.lead, x2.shape[1]) if ctx.needs_input_grad[0] else None
-        dw = (gy.t() @ x2).split(ctx.sizes, dim=0)
+        dw = weight_grad(gy, x2).split(ctx.sizes, dim=0)
         return dx, None, dw[0], dw[1], dw[2], gw[:d], gw[d:], None, None, None
 
 
@@ -493,7 +540,7 @@ def _v_forward(self: nn.Module, x: Tensor) -> Tensor:
 def fuse_model(model: nn.Module) -> dict[str, int]:
     """Rebind the forward of every RMSNorm module of an HF causal LM to the HIP kernel.  Returns what was
     rebound, by kind.  Call it before FSDP wrapping or after; parameters are left as they are."""
-    done = {"rmsnorm": 0, "rope": 0, "swiglu": 0, "qkv": 0}
+    done = {"rmsnorm": 0, "rope": 0, "swiglu": 0, "qkv": 0, "linear": 0}
     import sys
 
     home = sys.modules.get(type(model).__module__)  # e.g. transformers.models.qwen3.modeling_qwen3
@@ -517,6 +564,13 @@ def fuse_model(model: nn.Module) -> dict[str, int]:
             module._prl_torch_forward = module.forward
             module.forward = types.MethodType(_fused_mlp_forward, module)
             done["swiglu"] += 1
+        for attr in ("o_proj", "down_proj"):  # the blocks' other two products: only their weight gradient changes
+            lin = getattr(module, attr, None)
+            if isinstance(lin, nn.Linear) and lin.bias is None and not hasattr(lin, "_prl_torch_forward") \
+                    and (name.endswith("Attention") or name.endswith("MLP")):
+                lin._prl_torch_forward = lin.forward
+                lin.forward = types.MethodType(_split_dw_linear_forward, lin)
+                done["linear"] += 1
         projections = [getattr(module, a, None) for a in ("q_proj", "k_proj", "v_proj")]
         if name.endswith("Attention") and all(isinstance(m, nn.Linear) and m.bias is None for m in projections) \
                 and not hasattr(projections[0], "_prl_torch_forward"):

@@ -244,7 +244,7 @@ def test_fuse_model_rebinds_the_gated_mlps():
     cfg = T.model_config("Qwen/Qwen3-0.6B", num_layers=3)
     model = T.get_model(cfg, DEV, torch.bfloat16, seed=3)
     done = fused.fuse_model(model)
-    assert done == {"rmsnorm": 13, "rope": 1, "swiglu": 3, "qkv": 3}
+    assert done == {"rmsnorm": 13, "rope": 1, "swiglu": 3, "qkv": 3, "linear": 6}
     ids = torch.randint(0, 1000, (1, 64), device=DEV)
     pos = torch.arange(64, device=DEV)[None]
     timer = prl._capi.KernelTimer()
@@ -375,3 +375,20 @@ def test_qk_norm_rope_function_against_the_separate_steps(dtype):
     for name, g, w in zip("q k v dx dwq dwk dwv dnq dnk".split(), got, want):
         assert g.shape == w.shape, name
         assert (g - w).norm().item() <= tol * w.norm().item() + 1e-9, (name, (g - w).norm().item(), w.norm().item())
+
+
+def test_weight_gradient_split_over_the_tokens():
+    """`weight_grad` at a row long enough to be split, against the float32 product; and the short row left alone."""
+    gen = torch.Generator(device=DEV).manual_seed(12)
+    for rows, n_out, n_in in ((16384, 1024, 2048), (16384, 4096, 1024), (8192, 6144, 1024), (2048, 1024, 3072)):
+        gy = torch.randn(rows, n_out, generator=gen, device=DEV).to(torch.bfloat16)
+        x = torch.randn(rows, n_in, generator=gen, device=DEV).to(torch.bfloat16)
+        want = gy.float().t() @ x.float()
+        got = fused.weight_grad(gy, x)
+        one = gy.t() @ x
+        assert got.shape == want.shape and got.dtype == torch.bfloat16
+        err = (got.float() - want).norm().item() / want.norm().item()
+        base = (one.float() - want).norm().item() / want.norm().item()
+        assert err <= 1.6 * base + 1e-4, (rows, n_out, n_in, err, base)
+        if rows < 8192:
+            assert torch.equal(got, one)
