@@ -13,7 +13,8 @@
 // in-register reductions plus one exchange between the two lane halves, and the accumulators are already
 // the B operand of O^T = V^T P^T (rows of an accumulator tile = the k index of the next product).
 // Backward: two kernels.  `dq` has the forward's shape (S^T, dP^T = V dO^T, dS^T, dQ^T = K^T dS^T); `dkv`
-// runs one workgroup per (sample, key/value head), wave w owning keys 32w .. 32w+31, with the key on the
+// runs two workgroups per (sample, key/value head), one per half of the head dimension of the results, wave w
+// owning keys 32w .. 32w+31, with the key on the
 // lane (S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS) and sums over the query heads of the group
 // in registers, so nothing is added across workgroups and nothing needs an atomic.
 // Operands that a product consumes along the token index (V in the forward, K, Q and dO in the backward)
@@ -303,18 +304,25 @@ __global__ __launch_bounds__(kAThreads) void k_attn_short_bwd_dq(AttnView q, Att
   }
 }
 
-// dK and dV of one (sample, key/value head), summed over the G query heads that share it
-__global__ __launch_bounds__(kAThreads) void k_attn_short_bwd_dkv(AttnView q, AttnView k, AttnView v, AttnView dout,
-                                                                  const float* lse2, const float* delta,
-                                                                  uint16_t* dk, int64_t dk_ts, int64_t dk_hs,
-                                                                  uint16_t* dv, int64_t dv_ts, int64_t dv_hs,
-                                                                  const int32_t* cu, int Hkv, int G, int64_t T,
-                                                                  float c, float scale) {
+// dK and dV of one (sample, key/value head), summed over the G query heads that share it.  Two workgroups
+// per pair, each owning HALF of the head dimension of both results (64 accumulator registers instead of 128)
+// and staging one query head at a time (70 KB of LDS), so that two workgroups fit a compute unit (at most 256
+// registers per lane).  Both halves recompute the scores; the matrix cores are idle nine tenths of the time in
+// this kernel either way.  Measured against one workgroup per pair with both heads staged at once (360
+// registers, one workgroup per compute unit): 120 against 125 us per layer at 16 K tokens.
+__global__ __launch_bounds__(kAThreads, 2) void k_attn_short_bwd_dkv(AttnView q, AttnView k, AttnView v,
+                                                                     AttnView dout, const float* lse2,
+                                                                     const float* delta, uint16_t* dk, int64_t dk_ts,
+                                                                     int64_t dk_hs, uint16_t* dv, int64_t dv_ts,
+                                                                     int64_t dv_hs, const int32_t* cu, int Hkv, int G,
+                                                                     int64_t T, float c, float scale) {
   extern __shared__ __align__(16) uint16_t lds[];
-  // two query heads at a time: Q and dO of both are staged in one go (4 images), so a group of two heads costs
-  // one round of loads and two barriers instead of two rounds and four
-  float* row_stats = reinterpret_cast<float*>(lds + 4 * kAImg);  // [2 heads][lse, delta][128]
-  const int s = blockIdx.x / Hkv, hkv = blockIdx.x % Hkv;
+  uint16_t* Qs = lds;
+  uint16_t* Os = lds + kAImg;  // dO
+  float* row_lse = reinterpret_cast<float*>(lds + 2 * kAImg);
+  float* row_delta = row_lse + kAL;
+  const int dhalf = blockIdx.x & 1, pair = blockIdx.x >> 1;
+  const int s = pair / Hkv, hkv = pair % Hkv;
   int64_t start;
   int len;
   sample_range(cu, s, T, start, len);
@@ -328,57 +336,48 @@ __global__ __launch_bounds__(kAThreads) void k_attn_short_bwd_dkv(AttnView q, At
     vf[kk] = frag_global(v, start, len, hkv, key, kk, h);
   }
   const int qtiles = (len + 31) >> 5;
-  f32x16 dkt[4] = {}, dvt[4] = {};
-  for (int g0 = 0; g0 < G; g0 += 2) {
-    const int heads = G - g0 < 2 ? G - g0 : 2;
-    __syncthreads();  // the previous pair's images are no longer read
-    for (int j = 0; j < 2 * heads; ++j) {  // one image per round of 8 loads: 16 or 32 in flight measured 8 % slower here
-      uint16_t* const imgs[1] = {lds + j * kAImg};
-      const AttnView* const views[1] = {(j & 1) ? &dout : &q};
-      const int hs[1] = {hkv * G + g0 + (j >> 1)};
+  f32x16 dkt[2] = {}, dvt[2] = {};
+  for (int g = 0; g < G; ++g) {
+    const int hq = hkv * G + g;
+    __syncthreads();  // the previous head's images are no longer read
+    for (int j = 0; j < 2; ++j) {  // one image per round of loads: the registers a round needs are scarce here
+      uint16_t* const imgs[1] = {j ? Os : Qs};
+      const AttnView* const views[1] = {j ? &dout : &q};
+      const int hs[1] = {hq};
       stage_images<1>(imgs, views, start, len, hs);
     }
-    for (int j = 0; j < heads; ++j) {
-      const int hq = hkv * G + g0 + j;
-      if (threadIdx.x < kAL) {
-        const bool in = (int)threadIdx.x < len;
-        row_stats[(2 * j) * kAL + threadIdx.x] = in ? lse2[(int64_t)hq * T + start + threadIdx.x] : 0.0f;
-        row_stats[(2 * j + 1) * kAL + threadIdx.x] = in ? delta[(int64_t)hq * T + start + threadIdx.x] : 0.0f;
-      }
+    if (threadIdx.x < kAL) {
+      const bool in = (int)threadIdx.x < len;
+      row_lse[threadIdx.x] = in ? lse2[(int64_t)hq * T + start + threadIdx.x] : 0.0f;
+      row_delta[threadIdx.x] = in ? delta[(int64_t)hq * T + start + threadIdx.x] : 0.0f;
     }
     __syncthreads();
     if (32 * w < len) {  // wave-uniform: this wave has keys
-      for (int j = 0; j < heads; ++j) {
-        const uint16_t* Qs = lds + (2 * j) * kAImg;
-        const uint16_t* Os = lds + (2 * j + 1) * kAImg;  // dO
-        const float* row_lse = row_stats + (2 * j) * kAL;
-        const float* row_delta = row_stats + (2 * j + 1) * kAL;
+#pragma unroll 1
+      for (int mt = 0; mt < 4; ++mt) {  // query tiles; causal: only those at or after the wave's keys
+        if (mt >= w && mt < qtiles) {
+          f32x16 sa = {}, dp = {};
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {  // query tiles; causal: only those at or after the wave's keys
-          if (mt >= w && mt < qtiles) {
-            f32x16 sa = {}, dp = {};
+          for (int kk = 0; kk < 8; ++kk) {
+            sa = mfma(frag_rows(Qs, 32 * mt + r, kk, h), kf[kk], sa);  // S: rows = queries, lane = key
+            dp = mfma(frag_rows(Os, 32 * mt + r, kk, h), vf[kk], dp);  // dP = dO V^T
+          }
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-              sa = mfma(frag_rows(Qs, 32 * mt + r, kk, h), kf[kk], sa);  // S: rows = queries, lane = key
-              dp = mfma(frag_rows(Os, 32 * mt + r, kk, h), vf[kk], dp);  // dP = dO V^T
-            }
-            f32x16 pa, ds;
+          for (int i = 0; i < 16; ++i) {
+            const int query = 32 * mt + acc_row(i, h);
+            const bool valid = key <= query && query < len && key < len;
+            const float p = valid ? __builtin_amdgcn_exp2f(fmaf(sa[i], c, -row_lse[query])) : 0.0f;
+            sa[i] = p;
+            dp[i] = p * (dp[i] - row_delta[query]) * scale;  // dS
+          }
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-              const int query = 32 * mt + acc_row(i, h);
-              const bool valid = key <= query && query < len && key < len;
-              const float p = valid ? __builtin_amdgcn_exp2f(fmaf(sa[i], c, -row_lse[query])) : 0.0f;
-              pa[i] = p;
-              ds[i] = p * (dp[i] - row_delta[query]) * scale;
-            }
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 pf = acc_frag(sa, s2), df = acc_frag(dp, s2);
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-              const bf16x8 pf = acc_frag(pa, s2), df = acc_frag(ds, s2);
-#pragma unroll
-              for (int dt = 0; dt < 4; ++dt) {
-                dvt[dt] = mfma(frag_cols(Os, 32 * dt, 32 * mt, s2, lane), pf, dvt[dt]);  // dV^T += dO^T P
-                dkt[dt] = mfma(frag_cols(Qs, 32 * dt, 32 * mt, s2, lane), df, dkt[dt]);  // dK^T += Q^T dS
-              }
+            for (int dt = 0; dt < 2; ++dt) {
+              const int d0 = 32 * (2 * dhalf + dt);
+              dvt[dt] = mfma(frag_cols(Os, d0, 32 * mt, s2, lane), pf, dvt[dt]);  // dV^T += dO^T P
+              dkt[dt] = mfma(frag_cols(Qs, d0, 32 * mt, s2, lane), df, dkt[dt]);  // dK^T += Q^T dS
             }
           }
         }
@@ -386,10 +385,10 @@ __global__ __launch_bounds__(kAThreads) void k_attn_short_bwd_dkv(AttnView q, At
     }
   }
   if (key < len) {
-    uint16_t* krow = dk + (start + key) * dk_ts + hkv * dk_hs;
-    uint16_t* vrow = dv + (start + key) * dv_ts + hkv * dv_hs;
+    uint16_t* krow = dk + (start + key) * dk_ts + hkv * dk_hs + 64 * dhalf;
+    uint16_t* vrow = dv + (start + key) * dv_ts + hkv * dv_hs + 64 * dhalf;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
+    for (int dt = 0; dt < 2; ++dt) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         u32x2 pk;
@@ -410,7 +409,7 @@ static bool view_ok(const void* p, int64_t ts, int64_t hs) {
 
 constexpr size_t kFwdLds = 2 * kAImg * sizeof(uint16_t);
 constexpr size_t kDqLds = 2 * kAImg * sizeof(uint16_t);
-constexpr size_t kDkvLds = 4 * kAImg * sizeof(uint16_t) + 4 * kAL * sizeof(float);
+constexpr size_t kDkvLds = 2 * kAImg * sizeof(uint16_t) + 2 * kAL * sizeof(float);
 
 // The kernels use more than the 64 KB of LDS a launch gets by default; raised once per process and device.
 static int raise_lds_limits() {
@@ -500,7 +499,7 @@ extern "C" int prl_attn_short_bwd(const void* q, const int64_t* q_strides, const
                      (hipStream_t)stream, qv, kv, vv, ov, dov, lse2, delta, static_cast<uint16_t*>(dq), dq_strides[0],
                      dq_strides[1], cu_seqlens, q_heads, G, T, c, scale);
   PRL_CHECK_LAUNCH("attn_short_bwd (dq)");
-  hipLaunchKernelGGL(k_attn_short_bwd_dkv, dim3((unsigned)(n_samples * kv_heads)), dim3(kAThreads), kDkvLds,
+  hipLaunchKernelGGL(k_attn_short_bwd_dkv, dim3((unsigned)(2 * n_samples * kv_heads)), dim3(kAThreads), kDkvLds,
                      (hipStream_t)stream, qv, kv, vv, dov, lse2, delta, static_cast<uint16_t*>(dk), dk_strides[0],
                      dk_strides[1], static_cast<uint16_t*>(dv), dv_strides[0], dv_strides[1], cu_seqlens, kv_heads, G,
                      T, c, scale);
