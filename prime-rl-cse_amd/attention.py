@@ -38,7 +38,7 @@ class PackedPlan:
     equal: bool  # every sample has lmax tokens
     gather: Tensor | None  # [n * lmax] row position feeding each padded slot (ragged rows only)
     scatter: Tensor | None  # [total] padded slot of each row position
-    cu: Tensor | None = None  # int32 [n + 1] on the device: first token of every sample, then `total` (lmax <= 128 only)
+    cu: Tensor | None = None  # int32 [n + 1] on the device: first token of every sample, then `total`
     side_by_side: bool = True  # whether the padded layout at least halves the work of the masked row
 
 
@@ -53,8 +53,9 @@ def sample_starts(position_ids: Tensor) -> np.ndarray:
 
 
 def plan_from_position_ids(position_ids: Tensor, device: torch.device | str, max_work_ratio: float = 0.5):
-    """A `PackedPlan` for one packed row [1, T] of HOST position ids, or None when the side-by-side layout would
-    not at least halve the work (one long sample, or one sample much longer than the rest)."""
+    """A `PackedPlan` for one packed row [1, T] of HOST position ids (None for an empty row or a batch of rows):
+    the sample table every variable-length kernel takes and, where padding to the longest sample at least halves
+    the work of the masked row, the index tables of the side-by-side layout."""
     if position_ids.ndim == 2 and position_ids.shape[0] != 1:
         return None
     starts = sample_starts(position_ids)
@@ -64,12 +65,10 @@ def plan_from_position_ids(position_ids: Tensor, device: torch.device | str, max
         return None
     lengths = np.diff(np.concatenate([starts, [total]]))
     lmax = int(lengths.max())
-    cu = None
-    if lmax <= SHORT_MAX_LEN:
-        cu = torch.from_numpy(np.concatenate([starts, [total]]).astype(np.int32)).to(device, non_blocking=True)
+    cu = torch.from_numpy(np.concatenate([starts, [total]]).astype(np.int32)).to(device, non_blocking=True)
     side_by_side = n >= 2 and n * lmax * lmax <= max_work_ratio * total * total
     if not side_by_side:
-        return None if cu is None else PackedPlan(total, n, lmax, False, None, None, cu, False)
+        return PackedPlan(total, n, lmax, False, None, None, cu, False)
     if bool((lengths == lmax).all()):
         return PackedPlan(total, n, lmax, True, None, None, cu)
     offs = np.arange(lmax, dtype=np.int64)[None, :]
@@ -156,8 +155,37 @@ class _AttnShort(torch.autograd.Function):
         return dq, dk, dv, None, None, None
 
 
+def _varlen_attn():
+    """PyTorch's variable-length attention, or None (older torch, or PRL_ATTN_VARLEN=0 for A/B measurements)."""
+    import os
+
+    if os.environ.get("PRL_ATTN_VARLEN", "1") == "0":
+        return None
+    try:
+        from torch.nn.attention.varlen import varlen_attn
+    except Exception:
+        return None
+    return varlen_attn
+
+
+def varlen_attention_supported(query: Tensor, plan: "PackedPlan", scaling: float | None) -> bool:
+    if plan.cu is None or not query.is_cuda or query.dtype not in (torch.bfloat16, torch.float16):
+        return False
+    if scaling is not None and abs(float(scaling) - float(query.shape[3]) ** -0.5) > 1e-12:
+        return False  # the kernel's scale is fixed at 1 / sqrt(head dimension)
+    return _varlen_attn() is not None
+
+
+def varlen_attention(query: Tensor, key: Tensor, value: Tensor, plan: "PackedPlan") -> Tensor:
+    """[1, heads, T, d] in, [1, T, heads, d] out, through torch's varlen_attn on the packed row."""
+    rows = lambda x: x.squeeze(0).transpose(0, 1)  # [T, heads, d]
+    out = _varlen_attn()(rows(query), rows(key), rows(value), plan.cu, plan.cu, plan.lmax, plan.lmax, is_causal=True)
+    return out.unsqueeze(0)
+
+
 def short_attention_supported(query: Tensor, key: Tensor, plan: "PackedPlan") -> bool:
-    if plan.cu is None or not query.is_cuda or query.dtype != torch.bfloat16 or not _short_kernel_enabled():
+    if plan.cu is None or plan.lmax > SHORT_MAX_LEN or not query.is_cuda or query.dtype != torch.bfloat16 \
+            or not _short_kernel_enabled():
         return False
     from . import _capi as C
 
@@ -198,6 +226,8 @@ def packed_sdpa_attention(module: Any, query: Tensor, key: Tensor, value: Tensor
         return _HF_SDPA[0](module, query, key, value, attention_mask, dropout=dropout, scaling=scaling, **kwargs)
     if short_attention_supported(query, key, plan):
         return short_attention(query, key, value, plan, scaling), None
+    if varlen_attention_supported(query, plan, scaling):
+        return varlen_attention(query, key, value, plan), None
     if not plan.side_by_side:
         return _HF_SDPA[0](module, query, key, value, attention_mask, dropout=dropout, scaling=scaling, **kwargs)
     n, lmax = plan.n, plan.lmax

@@ -99,11 +99,17 @@ def test_short_attention_rejects_what_it_cannot_take():
     assert lib.prl_attn_short_supported(C.PRL_BF16 if hasattr(C, "PRL_BF16") else 1, 128, 128, 16, 8)
     for args in ((1, 64, 128, 16, 8), (1, 128, 129, 16, 8), (0, 128, 128, 16, 8), (1, 128, 128, 16, 3)):
         assert not lib.prl_attn_short_supported(*args)
+    q = torch.zeros(1, 16, 133, 128, dtype=torch.bfloat16, device=DEV)
+    k = torch.zeros(1, 8, 133, 128, dtype=torch.bfloat16, device=DEV)
     pos = torch.cat([torch.arange(n) for n in (129, 4)])[None]
-    assert attention.plan_from_position_ids(pos, DEV) is None  # a long sample that dominates: masked row
+    plan = attention.plan_from_position_ids(pos, DEV)  # a sample of 129 tokens: not for the short-sample kernels
+    assert not attention.short_attention_supported(q, k, plan) and not plan.side_by_side
+    assert attention.varlen_attention_supported(q, plan, 128 ** -0.5)
+    assert not attention.varlen_attention_supported(q, plan, 0.1)  # another score scale than 1 / sqrt(d)
+    assert not attention.varlen_attention_supported(q.float(), plan, None)
     pos = torch.cat([torch.arange(n) for n in (129, 100, 120, 90)])[None]
     plan = attention.plan_from_position_ids(pos, DEV)
-    assert plan is not None and plan.cu is None and plan.side_by_side  # side by side through SDPA
+    assert plan.side_by_side and plan.cu.tolist() == [0, 129, 229, 349, 439]
 
 
 @pytest.mark.parametrize("lengths", [[128] * 4, [50, 7, 31, 64, 2, 40, 60, 33, 48, 21, 128], [90]])

@@ -167,8 +167,10 @@ def test_fuse_model_patches_rope_and_whole_model_agrees():
     assert torch.equal(T.forward(model, ids, pos).float(), want)
 
 
-@pytest.mark.parametrize("lengths", [[32] * 6, [50, 7, 31, 64, 2, 40, 60, 33, 48, 21], [200]])
-def test_side_by_side_attention_gives_the_masked_row_attention(lengths):
+@pytest.mark.parametrize("path", ["best", "side_by_side"])
+@pytest.mark.parametrize("lengths", [[32] * 6, [50, 7, 31, 64, 2, 40, 60, 33, 48, 21], [200], [200, 150, 129, 140],
+                                     [300, 20, 20]])
+def test_side_by_side_attention_gives_the_masked_row_attention(lengths, path, monkeypatch):
     from prime_rl_cse_amd import attention
     from prime_rl_cse_amd import trainer as T
 
@@ -178,11 +180,15 @@ def test_side_by_side_attention_gives_the_masked_row_attention(lengths):
     gen = torch.Generator().manual_seed(t)
     ids = torch.randint(0, 1000, (1, t), generator=gen)
     pos = torch.cat([torch.arange(n) for n in lengths])[None]
+    if path == "side_by_side":  # neither the short-sample kernels nor varlen: SDPA over the padded layout
+        monkeypatch.setenv("PRL_ATTN_SHORT", "0")
+        monkeypatch.setenv("PRL_ATTN_VARLEN", "0")
     plan = attention.plan_from_position_ids(pos, DEV)
-    if len(lengths) == 1:
-        assert plan is None  # one sample: nothing to lay side by side
-        return
-    assert plan.n == len(lengths) and plan.lmax == max(lengths) and plan.equal == (len(set(lengths)) == 1)
+    assert plan.n == len(lengths) and plan.lmax == max(lengths) and plan.cu.tolist()[-1] == t
+    if plan.side_by_side:
+        assert plan.equal == (len(set(lengths)) == 1)
+    else:
+        assert len(lengths) == 1 or lengths == [300, 20, 20]  # one sample (dominates): no padded layout
     want = T.forward(model, ids.to(DEV), pos.to(DEV))
     want.float().square().mean().backward()
     grads = {n: p.grad.clone() for n, p in model.named_parameters()}
@@ -203,7 +209,8 @@ def test_plan_declines_when_padding_would_not_pay():
     from prime_rl_cse_amd import attention
 
     pos = torch.cat([torch.arange(900), torch.arange(50), torch.arange(50)])[None]
-    assert attention.plan_from_position_ids(pos, "cpu") is None  # one sample dominates: 3 * 900^2 > T^2 / 2
+    plan = attention.plan_from_position_ids(pos, "cpu")  # one sample dominates: 3 * 900^2 > T^2 / 2
+    assert not plan.side_by_side and plan.gather is None and plan.cu.tolist() == [0, 900, 950, 1000]
     pos = torch.cat([torch.arange(128)] * 16)[None]
     plan = attention.plan_from_position_ids(pos, "cpu")
     assert plan.equal and plan.n == 16 and plan.gather is None
