@@ -1,4 +1,4 @@
-"""Time of the short-sample attention kernels against PyTorch-ROCm's SDPA on the side-by-side layout, forward and
+"""Time of the short-sample attention kernels against PyTorch-ROCm's SDPA on the side-by-side layout and its varlen_attn, forward and
 backward, for rows of 128-token samples (Qwen3-0.6B heads: 16 query, 8 key / value, dimension 128).
 
     python tools/attn_bench.py [samples] [reps]        # also a convenient target for rocprofv3 --pmc
@@ -36,6 +36,11 @@ def sdpa():
     out.permute(0, 2, 1, 3).reshape(1, t, hq, d).backward(dout)
 
 
+def varlen():
+    out = attention.varlen_attention(q, k, v, plan)
+    out.backward(dout)
+
+
 def timed(fn):
     for _ in range(3):
         fn()
@@ -49,5 +54,5 @@ def timed(fn):
     return a.elapsed_time(b) / reps * 1e3
 
 
-print(f"{n} samples of {L} tokens: short-sample kernels {timed(ours):.1f} us, SDPA side by side {timed(sdpa):.1f} us "
-      f"(forward + backward, host launch overhead included)")
+print(f"{n} samples of {L} tokens: short-sample kernels {timed(ours):.1f} us, SDPA side by side {timed(sdpa):.1f} us, "
+      f"torch varlen_attn {timed(varlen):.1f} us (forward + backward, host launch overhead included)")
