@@ -61,10 +61,11 @@ def get_active_mm_params(config: Any) -> int:
             + config.kv_lora_rank * heads * (config.qk_nope_head_dim + config.v_head_dim)
         )
         o = layers * heads * config.v_head_dim * h
-    else:  # grouped-query attention
-        q = layers * h * heads * config.head_dim
-        kv = 2 * layers * h * config.num_key_value_heads * config.head_dim
-        o = layers * h * heads * config.head_dim
+    else:  # grouped-query attention; configs without an explicit head_dim (Qwen2) split the hidden size evenly
+        head_dim = getattr(config, "head_dim", None) or h // heads
+        q = layers * h * heads * head_dim
+        kv = 2 * layers * h * config.num_key_value_heads * head_dim
+        o = layers * h * heads * head_dim
     if hasattr(config, "first_k_dense_replace"):
         dense_layers = config.first_k_dense_replace
     elif hasattr(config, "num_experts_per_tok"):

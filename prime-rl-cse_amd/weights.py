@@ -90,7 +90,12 @@ class WeightPublisher:
     """Publishes HF-compatible bf16 weight files without stalling the step."""
 
     def __init__(self, output_dir: Path, interval: int | None = None, ckpt_interval: int | None = None,
-                 async_level: int = 2, device: torch.device | str | None = None):
+                 async_level: int = 2, device: torch.device | str | None = None, max_in_flight: int = 2):
+        """`max_in_flight` publications may be on their way to the disk at once; a further `publish` first waits
+        for the oldest (steps faster than the disk would otherwise pile up pinned host copies of the weights
+        without bound, and pinning fresh host memory for every publication costs more than the copy itself:
+        ~100 ms per 3 GB)."""
+        self.max_in_flight = max(1, int(max_in_flight))
         self.weights_dir = get_weights_dir(output_dir)
         self.interval, self.ckpt_interval, self.async_level = interval, ckpt_interval, async_level
         self.device = torch.device(device) if device is not None else None
@@ -120,6 +125,9 @@ class WeightPublisher:
 
         Returns at once.  Call `guard_parameters()` (or `pending.snapshot_done.synchronize()`) before the next
         in-place update of the parameters; the trainer loop in this package does."""
+        alive = [p for p in self._pending if p._thread is not None and p._thread.is_alive()]
+        while len(alive) >= self.max_in_flight:
+            alive.pop(0)._thread.join()
         pending = PendingPublication(step, get_weight_ckpt_model_path(self.weights_dir, step))
         state = state_dict if state_dict is not None else model.state_dict()
         side = self._side_stream()
@@ -128,7 +136,10 @@ class WeightPublisher:
             side.wait_stream(torch.cuda.current_stream(self.device))  # after the optimizer step
         with ctx, torch.no_grad():
             # 1. snapshot: bf16 copies of the local shards
-            snap = {k: (v.detach().to(dtype) if v.is_floating_point() else v.detach().clone()) for k, v in state.items()}
+            # (always a copy: parameters that already are in `dtype`, as the whole-model trainer's bf16 ones, would
+            # otherwise be read by the copy-out while the next optimizer step rewrites them)
+            snap = {k: (v.detach().to(dtype, copy=True) if v.is_floating_point() else v.detach().clone())
+                    for k, v in state.items()}
             if side is not None:
                 pending.snapshot_done = torch.cuda.Event()
                 pending.snapshot_done.record(side)
@@ -212,6 +223,9 @@ class WeightPublisher:
         if self.keep_step(old):
             return None
         path = get_step_path(self.weights_dir, old)
+        for p in self._pending:  # a publication of that step still being written: let it finish, then remove it
+            if p.step == old and p._thread is not None and p._thread.is_alive():
+                p._thread.join()
         shutil.rmtree(path, ignore_errors=True)
         return path
 

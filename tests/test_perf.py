@@ -16,6 +16,16 @@ def test_qwen3_0_6b_known_answers():
     assert perf.flop_per_token(QWEN3_0_6B, 1024) == 3_928_227_840
 
 
+def test_every_known_model_has_a_flop_count():
+    # Qwen2 configs carry no head_dim: the hidden size split over the heads stands in (7B: 3584 / 28 = 128)
+    from prime_rl_cse_amd import trainer as T
+
+    for name in T.MODEL_DIMS:
+        cfg = T.model_config(name)
+        assert perf.get_active_mm_params(cfg) > 0 and perf.flop_per_token(cfg, 128) > 6 * perf.get_active_mm_params(cfg)
+    assert perf.get_active_mm_params(T.model_config("Qwen/Qwen2.5-7B")) == 7070285824
+
+
 def test_mi355x_peaks_and_unknown_devices():
     assert perf.peak_bf16_flops("AMD Instinct MI355X") == 2.5e15
     assert perf.peak_bf16_flops("AMD Radeon Graphics gfx950:sramecc+:xnack-") == 2.5e15

@@ -58,6 +58,28 @@ def test_keep_and_clean_rule(tmp_path):
     assert no_rules.maybe_clean(6) == tmp_path / "weights" / "step_3"
 
 
+def test_publications_in_flight_are_bounded(tmp_path):
+    reset_world()
+    pub = WeightPublisher(tmp_path, async_level=8, max_in_flight=2)
+    big = nn.Sequential(*[nn.Linear(1024, 1024) for _ in range(24)])
+    pendings = [pub.publish(big, step=s) for s in range(5)]
+    alive = [p for p in pendings if p._thread.is_alive()]
+    assert len(alive) <= 2 and not pendings[0]._thread.is_alive()  # the early ones were waited for
+    pub.wait_all()
+    assert all((tmp_path / "weights" / f"step_{s}" / "pytorch_model.bin").exists() for s in range(5))
+
+
+def test_clean_waits_for_a_publication_still_being_written(tmp_path):
+    """Steps faster than the disk: the directory about to be removed may still be receiving its file."""
+    reset_world()
+    pub = WeightPublisher(tmp_path, async_level=0)
+    big = nn.Sequential(*[nn.Linear(1024, 1024) for _ in range(24)])
+    pending = pub.publish(big, step=0)
+    assert pub.maybe_clean(1) == tmp_path / "weights" / "step_0"  # step 1 considers step 0
+    assert pending.error is None and not (tmp_path / "weights" / "step_0").exists()
+    pending.wait(timeout=60)
+
+
 def _rank(rank, world, port, root, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world))
@@ -102,13 +124,15 @@ def test_two_ranks_gather_sharded_weights_over_gloo(tmp_path):
 
 
 @pytest.mark.gpu
-def test_side_stream_snapshot_is_not_disturbed_by_the_next_update(tmp_path):
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_side_stream_snapshot_is_not_disturbed_by_the_next_update(tmp_path, dtype):
     """The file holds the weights as they were at publish(); an optimizer-like in-place update issued right
-    afterwards (behind guard_parameters) must not leak into it."""
+    afterwards (behind guard_parameters) must not leak into it.  bf16 parameters (the whole-model trainer's)
+    need a copy just as fp32 ones need the cast."""
     reset_world()
     dev = torch.device("cuda:0")
     torch.manual_seed(1)
-    model = nn.Sequential(nn.Linear(1024, 1024), nn.Linear(1024, 1024)).to(dev)
+    model = nn.Sequential(nn.Linear(4096, 4096), nn.Linear(4096, 4096)).to(dev).to(dtype)
     before = {k: v.detach().to(torch.bfloat16).cpu() for k, v in model.state_dict().items()}
     pub = WeightPublisher(tmp_path, async_level=1, device=dev)
     seen = {}
