@@ -33,24 +33,6 @@ def log(msg: str) -> None:
         print(msg, flush=True)
 
 
-def model_config_of(config: RLTrainerConfig) -> Any:
-    """The transformers config of `config.model`: read from a local checkpoint directory in HF layout, or made
-    from literal dimensions for the reference's model names (there is no hub access here)."""
-    mc = config.model
-    attn = "sdpa"  # flash-attn is a CUDA package; packed rows go through attention.py or SDPA's block-diagonal mask
-    if Path(mc.name).is_dir():
-        from transformers import AutoConfig
-
-        cfg = AutoConfig.from_pretrained(mc.name)
-        cfg._attn_implementation, cfg.use_cache = attn, False
-        if mc.debug.num_layers is not None:
-            cfg.num_hidden_layers = min(mc.debug.num_layers, cfg.num_hidden_layers)
-        return cfg
-    if mc.name in T.MODEL_DIMS:
-        return T.model_config(mc.name, attn=attn, num_layers=mc.debug.num_layers)
-    raise ValueError(f"model {mc.name!r} is neither a local directory nor one of {sorted(T.MODEL_DIMS)}")
-
-
 def trainer_mode(config: RLTrainerConfig) -> str:
     """"replica" (the whole model on every GPU with HIP graphs, replica.py), "fsdp" (FSDP2 as the reference sets it
     up) or "auto" (replica where the model and optimizer allow it, else FSDP2).  A recipe asks for replica with
@@ -81,16 +63,38 @@ def fused_blocks(config: RLTrainerConfig) -> bool:
     return config.model.impl == "liger_kernel" or "impl" not in config.model.model_fields_set
 
 
+def model_config_of(config: RLTrainerConfig) -> Any:
+    """The transformers config of `config.model`: read from the checkpoint where one is on this machine (a
+    directory in HF layout, or the model's snapshot in the Hugging Face cache), else made from literal dimensions
+    for the architectures the reference's recipes name (there is no hub access here)."""
+    mc = config.model
+    attn = "sdpa"  # flash-attn is a CUDA package; packed rows go through attention.py or SDPA's block-diagonal mask
+    where = T.local_checkpoint(mc.name)
+    if where is not None:
+        from transformers import AutoConfig
+
+        cfg = AutoConfig.from_pretrained(where)
+        cfg._attn_implementation, cfg.use_cache = attn, False
+        if mc.debug.num_layers is not None:
+            cfg.num_hidden_layers = min(mc.debug.num_layers, cfg.num_hidden_layers)
+        return cfg
+    if T.known_architecture(mc.name) is not None:
+        return T.model_config(mc.name, attn=attn, num_layers=mc.debug.num_layers)
+    raise ValueError(f"model {mc.name!r}: no weights on this machine (directory or Hugging Face cache) and not one "
+                     f"of the known architectures {sorted(T.MODEL_DIMS) + sorted(T.MODEL_ALIASES)}")
+
+
 def build_model(config: RLTrainerConfig, device: torch.device, mesh: Any, dtype: torch.dtype | None = None,
                 for_training: bool = True, shard: bool = True):
     """The model of `config.model` on `device`; `shard=False` leaves it whole (for `replica.Replica`, or as the
     log-probability model beside one) instead of wrapping it in FSDP2."""
     mc = config.model
     cfg = model_config_of(config)
-    if Path(mc.name).is_dir():
+    where = T.local_checkpoint(mc.name)
+    if where is not None:
         from transformers import AutoModelForCausalLM
 
-        model = AutoModelForCausalLM.from_pretrained(mc.name, config=cfg, dtype=dtype or DTYPES[mc.optimization_dtype])
+        model = AutoModelForCausalLM.from_pretrained(where, config=cfg, dtype=dtype or DTYPES[mc.optimization_dtype])
         model.to(device)
     else:
         model = T.get_model(cfg, device, dtype or DTYPES[mc.optimization_dtype])

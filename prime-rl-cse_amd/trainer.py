@@ -49,12 +49,72 @@ MODEL_DIMS: dict[str, dict[str, Any]] = {
 }
 
 
+MODEL_DIMS.update({
+    # public model cards' dimensions for the other architectures the reference's recipes train
+    "Qwen/Qwen2.5-1.5B": dict(family="qwen2", vocab_size=151936, hidden_size=1536, intermediate_size=8960,
+                              num_hidden_layers=28, num_attention_heads=12, num_key_value_heads=2,
+                              tie_word_embeddings=True, rope_theta=1e6, rms_norm_eps=1e-6,
+                              max_position_embeddings=131072),
+    "Qwen/Qwen2.5-3B": dict(family="qwen2", vocab_size=151936, hidden_size=2048, intermediate_size=11008,
+                            num_hidden_layers=36, num_attention_heads=16, num_key_value_heads=2,
+                            tie_word_embeddings=True, rope_theta=1e6, rms_norm_eps=1e-6,
+                            max_position_embeddings=32768),
+    "Qwen/Qwen2.5-14B": dict(family="qwen2", vocab_size=152064, hidden_size=5120, intermediate_size=13824,
+                             num_hidden_layers=48, num_attention_heads=40, num_key_value_heads=8,
+                             tie_word_embeddings=False, rope_theta=1e6, rms_norm_eps=1e-5,
+                             max_position_embeddings=131072),
+    "Qwen/Qwen2.5-32B": dict(family="qwen2", vocab_size=152064, hidden_size=5120, intermediate_size=27648,
+                             num_hidden_layers=64, num_attention_heads=40, num_key_value_heads=8,
+                             tie_word_embeddings=False, rope_theta=1e6, rms_norm_eps=1e-5,
+                             max_position_embeddings=131072),
+})
+
+# Names the reference's recipes use (configs/**/train.toml, examples/**) for fine-tunes of these architectures.
+# They only matter when no weights are found on the machine and a random initialisation of the same shape
+# stands in (benchmarks, smoke runs); with weights present the checkpoint's own config is read.
+MODEL_ALIASES: dict[str, str] = {
+    "PrimeIntellect/Qwen3-0.6B": "Qwen/Qwen3-0.6B",
+    "PrimeIntellect/Qwen3-0.6B-Reverse-Text-SFT": "Qwen/Qwen3-0.6B",
+    "PrimeIntellect/Qwen3-1.7B": "Qwen/Qwen3-1.7B",
+    "PrimeIntellect/Qwen3-1.7B-Wordle-SFT": "Qwen/Qwen3-1.7B",
+    "deepseek-ai/DeepSeek-R1-Distill-Qwen-1.5B": "Qwen/Qwen2.5-1.5B",
+    "willcb/DeepSeek-R1-Distill-Qwen-1.5B": "Qwen/Qwen2.5-1.5B",
+    "deepseek-ai/DeepSeek-R1-Distill-Qwen-7B": "Qwen/Qwen2.5-7B",
+    "willcb/DeepSeek-R1-Distill-Qwen-7B": "Qwen/Qwen2.5-7B",
+    "willcb/DeepSeek-R1-Distill-Qwen-14B": "Qwen/Qwen2.5-14B",
+    "willcb/DeepSeek-R1-Distill-Qwen-32B": "Qwen/Qwen2.5-32B",
+}
+
+
+def known_architecture(name: str) -> str | None:
+    """The key of `MODEL_DIMS` that has the architecture of model `name`, or None."""
+    for candidate in (name, name.removesuffix("-Instruct"), name.removesuffix("-Base")):   # same shapes
+        if candidate in MODEL_DIMS:
+            return candidate
+    return MODEL_ALIASES.get(name)
+
+
+def local_checkpoint(name: str) -> str | None:
+    """Where the weights of `name` are on this machine: the directory itself, or its snapshot in the Hugging Face
+    cache (never the network: `local_files_only`), or None."""
+    from pathlib import Path
+
+    if Path(name).is_dir():
+        return name
+    try:
+        from huggingface_hub import snapshot_download
+
+        return snapshot_download(name, local_files_only=True)
+    except Exception:
+        return None
+
+
 def model_config(name: str, attn: str = "sdpa", num_layers: int | None = None, **overrides: Any):
     """A transformers config from literal dimensions; `num_layers` trims the depth
     (the reference's `model.debug.num_layers`, src/prime_rl/trainer/model.py:64-68)."""
     from transformers import Qwen2Config, Qwen3Config
 
-    dims = dict(MODEL_DIMS[name])
+    dims = dict(MODEL_DIMS[known_architecture(name) or name])
     dims.update(overrides)
     family = dims.pop("family")
     if num_layers is not None:

@@ -123,3 +123,27 @@ def test_trainer_mode_and_block_kernels_follow_the_recipe(monkeypatch):
     monkeypatch.setenv("PRL_TRAINER", "fsdp")
     monkeypatch.setenv("PRL_BLOCKS", "eager")
     assert trainer_mode(RLTrainerConfig(model={"compile": {}})) == "fsdp" and not fused_blocks(plain)
+
+
+def test_recipe_model_names_resolve_to_known_architectures(tmp_path):
+    """The names in the reference's recipes (configs/**/train.toml) build a config without the hub: from a local
+    checkpoint when there is one, else from literal dimensions of the same architecture."""
+    import pytest
+
+    from prime_rl_cse_amd import trainer as T
+    from prime_rl_cse_amd.settings import RLTrainerConfig
+    from prime_rl_cse_amd.train import model_config_of
+
+    cfg = model_config_of(RLTrainerConfig(model={"name": "PrimeIntellect/Qwen3-0.6B-Reverse-Text-SFT"}))
+    assert (cfg.hidden_size, cfg.num_hidden_layers, cfg.vocab_size, cfg.head_dim) == (1024, 28, 151936, 128)
+    cfg = model_config_of(RLTrainerConfig(model={"name": "willcb/DeepSeek-R1-Distill-Qwen-7B", "debug": {"num_layers": 3}}))
+    assert (cfg.hidden_size, cfg.num_hidden_layers, cfg.vocab_size) == (3584, 3, 152064)
+    assert all(T.known_architecture(n) in T.MODEL_DIMS for n in T.MODEL_ALIASES)
+    with pytest.raises(ValueError, match="no weights on this machine"):
+        model_config_of(RLTrainerConfig(model={"name": "nobody/unknown-model"}))
+    # a directory in HF layout wins over the literal dimensions
+    T.model_config("Qwen/Qwen3-0.6B", num_layers=2, hidden_size=64, intermediate_size=128, num_attention_heads=4,
+                   num_key_value_heads=2, head_dim=16, vocab_size=512).save_pretrained(tmp_path)
+    assert T.local_checkpoint(str(tmp_path)) == str(tmp_path)
+    cfg = model_config_of(RLTrainerConfig(model={"name": str(tmp_path)}))
+    assert (cfg.hidden_size, cfg.vocab_size, cfg.num_hidden_layers) == (64, 512, 2)
