@@ -139,10 +139,13 @@ class _SelectiveLogSoftmax(torch.autograd.Function):
         ctx.save_for_backward(logits, ids, lse)
         ctx.temperature, ctx.shift = temperature, shift
         ctx.mark_non_differentiable(ent)
+        ctx.set_materialize_grads(False)  # or autograd fills a zero gradient for the entropy on every backward
         return lp, ent
 
     @staticmethod
-    def backward(ctx, grad_lp: Tensor, _grad_ent):
+    def backward(ctx, grad_lp: Tensor | None, _grad_ent):
+        if grad_lp is None:
+            return None, None, None, None
         logits, ids, lse = ctx.saved_tensors
         return _launch_bwd(logits, ids, lse, grad_lp, None, ctx.temperature, ctx.shift), None, None, None
 
@@ -233,10 +236,13 @@ class _GrpoLoss(torch.autograd.Function):
         )
         ctx.save_for_backward(g)
         ctx.mark_non_differentiable(ratio, clipped, is_clipped)
+        ctx.set_materialize_grads(False)  # no zero-filled gradients for the three logged tensors
         return loss.reshape(()), ratio, clipped, is_clipped
 
     @staticmethod
     def backward(ctx, grad_loss, *_):
+        if grad_loss is None:
+            return (None,) * 9
         (g,) = ctx.saved_tensors
         return (g * grad_loss,) + (None,) * 8
 
@@ -417,10 +423,15 @@ class _PolicyLoss(torch.autograd.Function):
             ctx.save_for_backward(logits, ids.view(1, t), lse, g)
         ctx.temperature = temperature
         ctx.mark_non_differentiable(lp, ent, ratio, clipped, is_clipped, seg_start, n_seg)
+        # without this autograd launches seven fill kernels per backward (a zero "gradient" for each of the
+        # outputs above): 31 us per micro-batch next to a 220 us row kernel
+        ctx.set_materialize_grads(False)
         return f[8 * t].reshape(()), lp, ent, ratio, clipped, is_clipped, seg_start, n_seg
 
     @staticmethod
     def backward(ctx, grad_loss, *_):
+        if grad_loss is None:
+            return (None,) * 10
         gscale = grad_loss.to(torch.float32).reshape(1).contiguous()
         if ctx.single_pass:
             d = ctx.dlogits
