@@ -25,6 +25,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 from pathlib import Path
 
@@ -60,9 +61,12 @@ def parse() -> argparse.Namespace:
                    help="epilogue: the hot path from resident logits (the headline line); trainer: the whole "
                         "optimizer step with a random-init Qwen3-0.6B body under FSDP2")
     p.add_argument("--no-trainer-extra", action="store_true",
-                   help="at --gpus 1, do not append the short whole-trainer-step measurement to the line")
+                   help="do not append the short whole-trainer-step measurement to the line")
     p.add_argument("--trainer-steps", type=int, default=3)
-    p.add_argument("--trainer-impl", choices=["hf", "fused", "replica", "graphed"], default="graphed",
+    p.add_argument("--trainer-limit", type=float, default=300.0,
+                   help="with --gpus N > 1: seconds after which the line is printed without the whole-trainer-step "
+                        "extra and the process ends")
+    p.add_argument("--trainer-impl", choices=["hf", "fused", "replica", "graphed"], default="replica",
                    help="whole-trainer-step workload: hf = the transformers blocks as they are under FSDP2; fused = "
                         "their RMSNorm / rotary / SwiGLU on this package's HIP kernels (the reference's model.impl = "
                         "liger_kernel); replica = fused, the whole model on every GPU with sharded master weights; "
@@ -172,7 +176,7 @@ def pmc_traffic(kernel: str, logits_dtype: str) -> tuple[float | None, str | Non
 
 
 def trainer_measure(dev, world: int, steps: int, warmup: int, cpu: bool, cpu_seconds: float,
-                    impl: str = "graphed") -> dict:
+                    impl: str = "replica") -> dict:
     """The whole optimizer step of the Qwen3-0.6B reverse_text recipe on synthetic rollouts: transformer body by
     PyTorch-ROCm (random init, bf16 compute under FSDP2, fp32 master weights and gradient reduction), everything
     after the LM head by this package, gradient clipping and AdamW (src/prime_rl/trainer/rl/train.py:259-352)."""
@@ -183,7 +187,7 @@ def trainer_measure(dev, world: int, steps: int, warmup: int, cpu: bool, cpu_sec
     os.environ.setdefault("MASTER_PORT", "29577")
     os.environ.setdefault("RANK", "0")
     os.environ.setdefault("WORLD_SIZE", "1")
-    mesh = T.init_distributed(dev)
+    mesh = T.init_distributed(dev) if impl in ("hf", "fused") else None  # the replica reduces over the default group
     cfg = T.model_config("Qwen/Qwen3-0.6B")
     model = T.get_model(cfg, dev, torch.float32, seed=0)
     fused_modules = {}
@@ -228,7 +232,8 @@ def trainer_measure(dev, world: int, steps: int, warmup: int, cpu: bool, cpu_sec
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64,
+                      device=dev if world == 1 or dist.get_backend() == "nccl" else "cpu")  # gloo: host tensors only
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     sec = float(el.item()) / steps
@@ -388,6 +393,7 @@ def main() -> None:
     ms_per_step = elapsed / args.steps * 1e3
     value = world * BATCH / (elapsed / args.steps)
 
+    line = None
     if rank == 0:
         t = MICRO_BATCH * SEQ_LEN
         k = side.summary()
@@ -459,17 +465,46 @@ def main() -> None:
                                        if k in last_stats}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(rows, args.cpu_seconds)
-        if world == 1 and not args.no_trainer_extra:
-            del rows
-            torch.cuda.empty_cache()
-            try:
-                line["trainer_step"] = trainer_measure(dev, 1, args.trainer_steps, 2, not args.no_cpu_baseline,
-                                                       args.cpu_seconds, args.trainer_impl)
-            except Exception as exc:  # the headline line must not depend on the transformers install
-                line["trainer_step"] = {"error": f"{type(exc).__name__}: {exc}"}
-        print(json.dumps(line), flush=True)
+    del rows
+    torch.cuda.empty_cache()
+
+    # The whole-trainer-step extra runs on every rank (with more than one, the end of its step is a reduce-scatter
+    # and an all-gather over RCCL).  The headline line must survive whatever happens in there: an exception is
+    # reported inside the line, and with several ranks a watchdog prints the line without the extra and ends the
+    # process if the extra, or the final barrier after a failure on another rank, has not come back in time.
+    state = {"printed": False}
+    lock = threading.Lock()
+
+    def emit() -> None:
+        with lock:
+            if rank == 0 and not state["printed"]:
+                state["printed"] = True
+                print(json.dumps(line), flush=True)
+
+    def bail() -> None:
+        if rank == 0:
+            line.setdefault("trainer_step", {"error": f"no result within {args.trainer_limit:.0f} s"})
+        emit()
+        os._exit(0)
+
+    watchdog = None
+    if world > 1 and not args.no_trainer_extra:
+        watchdog = threading.Timer(args.trainer_limit, bail)
+        watchdog.daemon = True
+        watchdog.start()
+    if not args.no_trainer_extra:
+        try:
+            info = trainer_measure(dev, world, args.trainer_steps, 2, world == 1 and not args.no_cpu_baseline,
+                                   args.cpu_seconds, args.trainer_impl)
+        except Exception as exc:  # e.g. a transformers install that lacks the model
+            info = {"error": f"{type(exc).__name__}: {exc}"}
+        if rank == 0:
+            line["trainer_step"] = info
+    emit()
     if dist.is_initialized():
         dist.barrier()
+        if watchdog is not None:
+            watchdog.cancel()
         dist.destroy_process_group()
 
 

@@ -100,6 +100,15 @@ class FlatState:
     def _gloo(self) -> bool:
         return dist.is_initialized() and dist.get_backend(self.group) == "gloo"
 
+    def _gather_compute_copy(self) -> None:
+        """Every rank's new shard of the compute copy into every rank's `flat16`."""
+        if self._gloo():  # gloo gets host tensors only
+            parts = [torch.empty(self.shard, dtype=self.flat16.dtype) for _ in range(self.world)]
+            dist.all_gather(parts, self._shard16.cpu(), group=self.group)
+            self.flat16.copy_(torch.cat(parts))
+        else:
+            dist.all_gather_into_tensor(self.flat16, self._shard16, group=self.group)
+
     def finish_step(self, optimizer: torch.optim.Optimizer, max_norm: float | None) -> Tensor:
         """Mean of the ranks' gradient sums, clip by the global norm, optimizer step on the shard, new compute
         copy on every rank.  Returns the gradient norm before clipping (a 0-d tensor on the device; reading it
@@ -107,24 +116,30 @@ class FlatState:
         which the reference calls (src/prime_rl/trainer/rl/train.py:336-338)."""
         if self.world > 1:
             grad = self._shard_grad
-            if self._gloo():  # no reduce-scatter in gloo: reduce everything, keep the own part
-                dist.all_reduce(self.acc32, group=self.group)
+            if self._gloo():  # no reduce-scatter in gloo: reduce everything (on the host), keep the own part
+                total = self.acc32.cpu()
+                dist.all_reduce(total, group=self.group)
                 lo = self.rank * self.shard
-                grad.copy_(self.acc32[lo : lo + self.shard]).div_(self.world)
+                grad.copy_(total[lo : lo + self.shard]).div_(self.world)
             else:
                 dist.reduce_scatter_tensor(grad, self.acc32, op=dist.ReduceOp.AVG, group=self.group)
         else:
             grad = self.acc32
         sq = torch.linalg.vector_norm(grad, 2, dtype=torch.float32).square()
         if self.world > 1:
-            dist.all_reduce(sq, group=self.group)
+            if self._gloo():
+                host = sq.cpu()
+                dist.all_reduce(host, group=self.group)
+                sq = host.to(sq.device)
+            else:
+                dist.all_reduce(sq, group=self.group)
         norm = sq.sqrt()
         coef = torch.clamp(max_norm / (norm + 1e-6), max=1.0).reshape(1) if max_norm is not None else None
         if hasattr(optimizer, "step_flat"):
             # clipping, the update, the new compute copy and (one rank) the clearing of the sums in one launch
             if self.world > 1:
                 optimizer.step_flat(grad, coef, self._shard16)
-                dist.all_gather_into_tensor(self.flat16, self._shard16, group=self.group)
+                self._gather_compute_copy()
                 self.acc32.zero_()
             else:
                 optimizer.step_flat(grad, coef, self.flat16, zero_grad=True)
@@ -136,10 +151,7 @@ class FlatState:
         self.master.grad = None
         if self.world > 1:
             self._shard16.copy_(self.master.detach())
-            if self._gloo():
-                dist.all_gather(list(self.flat16.chunk(self.world)), self._shard16, group=self.group)
-            else:
-                dist.all_gather_into_tensor(self.flat16, self._shard16, group=self.group)
+            self._gather_compute_copy()
         else:
             self.flat16.copy_(self.master.detach())
         self.acc32.zero_()
@@ -156,6 +168,7 @@ class _Captured:
         self.loss: Tensor | None = None
         self.aux: dict[str, Tensor] = {}
         self.src: Tensor | None = None
+        self.embed_grad: Tensor | None = None  # gradient of the looked-up embedding rows, [1, T, H]
 
 
 _TENSOR_KEYS = ("input_ids", "position_ids", "advantages", "logprobs", "loss_mask")
@@ -165,7 +178,7 @@ _AUX_KEYS = ("logprobs", "entropy", "importance_ratio", "clipped_importance_rati
 class Replica:
     """The training side of one rank: model, flat state, optimizer and the micro-batch graphs."""
 
-    def __init__(self, model: nn.Module, optimizer_factory: Any, group: Any = None, graphs: bool = True,
+    def __init__(self, model: nn.Module, optimizer_factory: Any, group: Any = None, graphs: bool = False,
                  max_graphs: int = 4, compute_dtype: torch.dtype = torch.bfloat16):
         """`model` on the GPU in any floating dtype (its values seed the fp32 master weights);
         `optimizer_factory(module)` builds the optimizer over `module.parameters()`; `compute_dtype` is what
@@ -201,17 +214,30 @@ class Replica:
 
     # ------------------------------------------------------------------ one micro-batch
 
-    def _forward_backward(self, mb: dict[str, Any], plan: Any, loss_config: LossConfig) -> tuple[Tensor, dict, list]:
+    def _forward_backward(self, mb: dict[str, Any], plan: Any, loss_config: LossConfig
+                          ) -> tuple[Tensor, dict, list, Tensor]:
+        """Forward, loss and backward of one row.  Returns the loss, the per-token results, the parameters'
+        gradients and the gradient of the looked-up embedding rows [1, T, H].
+
+        The embedding table's own gradient is NOT formed in here.  torch computes it with rocPRIM's
+        unique-by-key, which clears two counters with hipMemsetAsync; as a node of a replayed graph that memset
+        has left them uncleared (output offsets taken from stale memory: a memory fault).  So the rows are looked
+        up without autograd and enter the model as a leaf, and `_embedding_backward` turns their gradient into
+        the table's, eagerly, after the pass.  Eager passes do the same, so that both kinds of pass add the same
+        numbers in the same order."""
         from .trainer import forward
 
-        logits = forward(self.model, mb["input_ids"], mb["position_ids"], plan)
+        with torch.no_grad():
+            rows = self.model.get_input_embeddings()(mb["input_ids"])
+        rows.requires_grad_(True)
+        logits = forward(self.model, None, mb["position_ids"], plan, rows)
         # normaliser 1 here: the step's own normaliser multiplies the gradients when they are accumulated
         loss, aux = policy_loss(logits, mb["input_ids"], mb["position_ids"], mb["advantages"], mb["logprobs"],
                                 mb["loss_mask"], mb["temperature"], loss_config, 1.0, skip_masked=True)
         del logits
         loss.backward(unit_gradient(self.device))
         grads = [p.grad for p in self.state.params]
-        return loss.detach(), aux, grads
+        return loss.detach(), aux, grads, rows.grad
 
     def _grad_pointers(self, grads: list) -> list[int]:
         dt = self.state.flat16.dtype
@@ -235,6 +261,19 @@ class Replica:
                                    C.stream_ptr(self.device)),
                 "prl_accumulate",
             )
+
+    def _embedding_backward(self, input_ids: Tensor, grad_rows: Tensor) -> None:
+        """The embedding table's share of a micro-batch's gradient, from the gradient of the looked-up rows:
+        torch's own (sorted, deterministic) embedding backward, run eagerly, then added to the flat sum like any
+        other gradient (for tied weights, on top of the LM head's share that the graph has added)."""
+        table = self.model.get_input_embeddings()
+        pad = -1 if table.padding_idx is None else int(table.padding_idx)
+        grad = torch.ops.aten.embedding_dense_backward(grad_rows.reshape(-1, grad_rows.shape[-1]),
+                                                       input_ids.reshape(-1), table.weight.shape[0], pad, False)
+        ptrs = [grad.data_ptr() if p is table.weight else 0 for p in self.state.params]
+        if not any(ptrs):
+            raise RuntimeError("Replica: the embedding table is not among the model's parameters")
+        self._accumulate(torch.tensor(ptrs, dtype=torch.int64).to(self.device))
 
     def _drop_grads(self) -> None:
         for p in self.state.params:
@@ -260,7 +299,7 @@ class Replica:
         cap.src = torch.zeros(len(self.state.params), dtype=torch.int64, device=self.device)
         cap.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(cap.graph):
-            cap.loss, cap.aux, grads = self._forward_backward(cap.inputs, cap.plan, loss_config)
+            cap.loss, cap.aux, grads, cap.embed_grad = self._forward_backward(cap.inputs, cap.plan, loss_config)
             ptrs = self._grad_pointers(grads)
             self._accumulate(cap.src)
             del grads
@@ -297,12 +336,14 @@ class Replica:
                     if getattr(plan, name) is not None:
                         getattr(cap.plan, name).copy_(getattr(plan, name))
             cap.graph.replay()
+            self._embedding_backward(cap.inputs["input_ids"], cap.embed_grad)
             self.replays += 1
             return cap.loss.clone(), {k: cap.aux[k].clone() for k in _AUX_KEYS}
-        loss, aux, grads = self._forward_backward(mb, plan, loss_config)
+        loss, aux, grads, embed_grad = self._forward_backward(mb, plan, loss_config)
         src = torch.tensor(self._grad_pointers(grads), dtype=torch.int64).to(self.device)
         self._accumulate(src)
-        del grads
+        self._embedding_backward(mb["input_ids"], embed_grad)
+        del grads, embed_grad
         self._drop_grads()
         self.eager_runs += 1
         return loss, aux

@@ -34,7 +34,7 @@ def log(msg: str) -> None:
 
 
 def trainer_mode(config: RLTrainerConfig) -> str:
-    """"replica" (the whole model on every GPU with HIP graphs, replica.py), "fsdp" (FSDP2 as the reference sets it
+    """"replica" (the whole model on every GPU, replica.py), "fsdp" (FSDP2 as the reference sets it
     up) or "auto" (replica where the model and optimizer allow it, else FSDP2).  A recipe asks for replica with
     `[model.compile]`, the reference's switch for its tracing compiler, and for FSDP2 by setting
     `model.reshard_after_forward` (either way: it then cares how FSDP2 treats its parameters); PRL_TRAINER
@@ -49,6 +49,20 @@ def trainer_mode(config: RLTrainerConfig) -> str:
     if "reshard_after_forward" in config.model.model_fields_set:
         return "fsdp"
     return "auto"
+
+
+def replay_graphs(config: RLTrainerConfig) -> bool:
+    """Whether the whole-model trainer replays its micro-batches from HIP graphs: only when asked, by
+    `[model.compile]` in the recipe (the reference's opt-in for its tracing compiler) or PRL_GRAPHS=1;
+    PRL_GRAPHS=0 overrides the recipe.  Off otherwise: with a step's rows joined into one pass replay saves about
+    1 %, and a captured graph holds the memset nodes that library calls record (hipBLASLt's stream-K products
+    clear their flags that way), which this build's own kernels avoid inside graphs."""
+    import os
+
+    env = os.environ.get("PRL_GRAPHS", "")
+    if env in ("0", "1"):
+        return env == "1"
+    return config.model.compile is not None
 
 
 def fused_blocks(config: RLTrainerConfig) -> bool:
@@ -161,8 +175,10 @@ def _train(config: RLTrainerConfig, world: Any, device: torch.device, mesh: Any)
         reason = eligible(T.get_model(model_config_of(config), "meta"), config.optim.type, config.model.ac is not None)
         if reason is None:
             model, model_cfg = build_model(config, device, mesh, shard=False)
-            replica = Replica(model, lambda m: setup_optimizer(config.optim, m, flat=True))
-            log("whole model per GPU, master weights and optimizer state sharded, micro-batches from HIP graphs")
+            graphs = replay_graphs(config)
+            replica = Replica(model, lambda m: setup_optimizer(config.optim, m, flat=True), graphs=graphs)
+            log("whole model per GPU, master weights and optimizer state sharded"
+                + (", micro-batches from HIP graphs" if graphs else ""))
         elif mode == "replica" or config.model.compile is not None:
             log(f"whole-model mode not possible ({reason}); FSDP2")
     if replica is None:

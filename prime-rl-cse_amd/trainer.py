@@ -185,17 +185,20 @@ def setup_fsdp(model: nn.Module, mesh: Any, reduce_dtype: torch.dtype = torch.fl
     return model
 
 
-def forward(model: nn.Module, input_ids: Tensor, position_ids: Tensor, plan: Any = None) -> Tensor:
+def forward(model: nn.Module, input_ids: Tensor | None, position_ids: Tensor, plan: Any = None,
+            inputs_embeds: Tensor | None = None) -> Tensor:
     """Logits [batch, seq, vocab] of a packed row (src/prime_rl/trainer/model.py:251-254).  With a
     `attention.PackedPlan` of that row, attention runs over the samples side by side instead of over the
-    whole row under a [T, T] mask; the logits are the same."""
+    whole row under a [T, T] mask; the logits are the same.  `inputs_embeds` (the rows of the embedding table,
+    already looked up) takes the place of `input_ids`."""
+    tokens = {"input_ids": input_ids} if inputs_embeds is None else {"inputs_embeds": inputs_embeds}
     if plan is None:
-        return model(input_ids=input_ids, position_ids=position_ids).logits
+        return model(position_ids=position_ids, **tokens).logits
     from . import attention
 
     attention.install()
     with attention.use_plan(plan):
-        return model(input_ids=input_ids, position_ids=position_ids).logits
+        return model(position_ids=position_ids, **tokens).logits
 
 
 def attention_plan(host_micro_batch: MicroBatch, device: torch.device | str) -> Any:

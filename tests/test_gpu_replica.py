@@ -101,7 +101,8 @@ def test_fp32_replica_step_matches_cpu_model_with_oracle_loss(ratio_type, join):
         cpu_losses.append(loss.item())
     cpu_norm = torch.nn.utils.clip_grad_norm_(cpu_model.parameters(), 1e9).item()
 
-    rep = Replica(gpu_model, lambda m: torch.optim.SGD(m.parameters(), lr=1.0), compute_dtype=torch.float32)
+    rep = Replica(gpu_model, lambda m: torch.optim.SGD(m.parameters(), lr=1.0), graphs=True,
+                  compute_dtype=torch.float32)
     before = rep.state.master.detach().clone()
     res = rep.train_step(mbs, loss_cfg, max_norm=1e9, join_tokens=join)
     # apart: eager, capture + replay, replay, replay; joined: the four rows are one row of 256 tokens

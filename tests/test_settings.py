@@ -120,6 +120,15 @@ def test_trainer_mode_and_block_kernels_follow_the_recipe(monkeypatch):
     plain = RLTrainerConfig()
     assert trainer_mode(plain) == "auto" and fused_blocks(plain)
     assert trainer_mode(RLTrainerConfig(model={"compile": {}})) == "replica"
+    from prime_rl_cse_amd.train import replay_graphs
+
+    monkeypatch.delenv("PRL_GRAPHS", raising=False)
+    assert replay_graphs(RLTrainerConfig(model={"compile": {}})) and not replay_graphs(RLTrainerConfig())
+    monkeypatch.setenv("PRL_GRAPHS", "0")
+    assert not replay_graphs(RLTrainerConfig(model={"compile": {}}))
+    monkeypatch.setenv("PRL_GRAPHS", "1")
+    assert replay_graphs(RLTrainerConfig())
+    monkeypatch.delenv("PRL_GRAPHS")
     assert trainer_mode(RLTrainerConfig(model={"reshard_after_forward": True})) == "fsdp"
     assert not fused_blocks(RLTrainerConfig(model={"impl": "hf"}))
     assert fused_blocks(RLTrainerConfig(model={"impl": "liger_kernel"}))
