@@ -264,6 +264,9 @@ class WeightBroadcast:
 
     def __init__(self, group: Any, src: int, device: torch.device | str):
         self.group, self.src, self.device = group, src, torch.device(device)
+        if self.device.type == "cuda" and dist.get_backend(group) == "gloo":
+            raise ValueError("WeightBroadcast: a gloo group moves host tensors only (device='cpu'); "
+                             "device buckets need an RCCL (\"nccl\") group")
         self.is_sender = dist.get_rank() == src
         self.is_member = dist.get_rank(group) >= 0 if group is not None else True
         self.manifest: list[tuple[str, tuple[int, ...], torch.dtype, int, int]] | None = None
