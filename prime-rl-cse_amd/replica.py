@@ -352,15 +352,23 @@ class Replica:
 
     def train_step(self, micro_batches: list[MicroBatch], loss_config: LossConfig, max_norm: float | None = 1.0,
                    scheduler: Any = None, samples: int | None = None,
-                   recomputed_errors: list[Tensor] | None = None, join_tokens: int | None = None) -> Any:
+                   recomputed_errors: list[Tensor] | None = None, join_tokens: int | None = None,
+                   skip_unscored: bool = True) -> Any:
         """One optimizer step over this rank's micro-batches (src/prime_rl/trainer/rl/train.py:259-364);
-        same results and the same `StepResult` as `trainer.train_step`, micro-batches joined the same way."""
+        same results and the same `StepResult` as `trainer.train_step`, micro-batches joined the same way and
+        fillers left out the same way (`trainer.scored`)."""
         from .trainer import (MERGE_MAX_TOKENS, StepResult, attention_plan, join_micro_batches, join_per_row,
-                              local_loss_scale, restore_row_starts)
+                              local_loss_scale, restore_row_starts, scored)
 
         join_tokens = MERGE_MAX_TOKENS if join_tokens is None else join_tokens
         t0 = time.perf_counter()
+        n_given = len(micro_batches)
         inv_scale = 1.0 / max(float(local_loss_scale(micro_batches, loss_config)), 1.0)
+        if skip_unscored:
+            keep = scored(micro_batches)
+            micro_batches = [micro_batches[i] for i in keep]
+            if recomputed_errors is not None:
+                recomputed_errors = [recomputed_errors[i] for i in keep]
         self._scale.fill_(inv_scale)
         tensors = Tensors()
         tokens = 0
@@ -388,13 +396,15 @@ class Replica:
                 for key in ("importance_ratio", "clipped_importance_ratio", "is_clipped"):
                     tensors.add(key, aux[key], mask)
             tokens += int(mb["input_ids"].numel())
+        if n_given > len(micro_batches):  # every filler left out: a loss of 0, as the reference logs for it
+            tensors.add("loss", torch.zeros(n_given - len(micro_batches), dtype=torch.float32, device=self.device))
         grad_norm = self.state.finish_step(self.optimizer, max_norm)
         if scheduler is not None:
             scheduler.step()
         stats = tensors.compute_stats()
         seconds = time.perf_counter() - t0
         if samples is None:
-            samples = len(micro_batches)
+            samples = n_given
         return StepResult(loss=stats.get("loss/mean", float("nan")), grad_norm=float(grad_norm), stats=stats,
                           seconds=seconds, tokens=tokens, samples=samples, passes=len(units))
 

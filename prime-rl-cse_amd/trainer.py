@@ -234,6 +234,20 @@ def local_loss_scale(micro_batches: list[MicroBatch], loss_config: LossConfig) -
     return int(micro_batches[0]["input_ids"].shape[0] * len(micro_batches))
 
 
+def scored(micro_batches: list[MicroBatch]) -> list[int]:
+    """Indices of the micro-batches that can change anything: those with at least one unmasked token.
+
+    The orchestrator pads every step with filler micro-batches, copies of the first one with advantage 0 and an
+    all-False mask (src/prime_rl/orchestrator/batch.py:153-161: `W - n % W` of them, so a whole extra round when
+    the count already divides), because FSDP's collectives need the same number of passes on every rank.  A
+    micro-batch without an unmasked token has loss 0 and gradient 0, and every logged statistic is taken under the
+    mask (src/prime_rl/trainer/rl/train.py:313-333), so where the number of passes is a rank's own business such a
+    pass only costs time: the caller runs the others and logs a loss of 0 for each one left out.  The masks are
+    still on the host here.  If no micro-batch has an unmasked token, all are kept (a step needs a pass)."""
+    keep = [i for i, mb in enumerate(micro_batches) if bool(mb["loss_mask"].any())]
+    return keep if keep else list(range(len(micro_batches)))
+
+
 MERGE_MAX_TOKENS = 16384  # longest joined row (the one-launch loss kernel's limit, 5 GB of bf16 logits at V = 152 K)
 
 
@@ -334,14 +348,18 @@ def restore_row_starts(rows: JoinedRows, mb: dict[str, Any], aux: dict[str, Tens
 def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, micro_batches: list[MicroBatch],
                loss_config: LossConfig, max_norm: float = 1.0, device: torch.device | str = "cuda",
                scheduler: Any = None, samples: int | None = None,
-               recomputed_errors: list[Tensor] | None = None, join_tokens: int = MERGE_MAX_TOKENS) -> StepResult:
+               recomputed_errors: list[Tensor] | None = None, join_tokens: int = MERGE_MAX_TOKENS,
+               skip_unscored: bool = True) -> StepResult:
     """One optimizer step over this rank's micro-batches
     (src/prime_rl/trainer/rl/train.py:259-364).  `recomputed_errors` are the
     per-micro-batch tensors `recompute_logprobs` returned; they are logged as
     `recomputed_logprob_error` (train.py:316-318).  In token mode consecutive
     micro-batches are joined into rows of up to `join_tokens` tokens and run as
-    one (`join_micro_batches`; 0 keeps them apart)."""
+    one (`join_micro_batches`; 0 keeps them apart).  Micro-batches without an
+    unmasked token (the orchestrator's fillers) are not run where that is this
+    rank's own business (`scored`; `skip_unscored=False` runs them)."""
     t0 = time.perf_counter()
+    n_given = len(micro_batches)
     loss_scale = local_loss_scale(micro_batches, loss_config)
     tensors = Tensors()
     tokens = 0
@@ -351,6 +369,13 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, micro_batches
     # number of passes on every rank, so there the micro-batches stay apart.
     one_rank = not dist.is_initialized() or dist.get_world_size() == 1
     passes_are_local = one_rank or getattr(model, "_prl_keep_gathered", False) or not hasattr(model, "unshard")
+    left_out = 0
+    if passes_are_local and skip_unscored:
+        keep = scored(micro_batches)
+        left_out = len(micro_batches) - len(keep)
+        micro_batches = [micro_batches[i] for i in keep]
+        if recomputed_errors is not None:
+            recomputed_errors = [recomputed_errors[i] for i in keep]
     rows = join_micro_batches(micro_batches, join_tokens) \
         if loss_config.ratio_type == "token" and join_tokens > 0 and passes_are_local else None
     units = [r.micro_batch for r in rows] if rows is not None else micro_batches
@@ -387,6 +412,8 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, micro_batches
             for key in ("importance_ratio", "clipped_importance_ratio", "is_clipped"):
                 tensors.add(key, aux[key], mask)
         tokens += int(mb["input_ids"].numel())
+    if left_out:
+        tensors.add("loss", torch.zeros(left_out, dtype=torch.float32, device=device))
     grad_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=max_norm)
     if hasattr(grad_norm, "full_tensor"):
         grad_norm = grad_norm.full_tensor()
@@ -399,7 +426,7 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, micro_batches
     if samples is None:
         # a packed row carries as many rollouts as it has position resets; for the
         # synthetic loader that is the micro-batch size
-        samples = len(micro_batches)
+        samples = n_given
     return StepResult(loss=stats.get("loss/mean", float("nan")), grad_norm=float(grad_norm), stats=stats,
                       seconds=seconds, tokens=tokens, samples=samples, passes=len(units))
 
@@ -420,6 +447,10 @@ def recompute_logprobs(logprob_model: nn.Module, micro_batches: list[MicroBatch]
 
     one_rank = not dist.is_initialized() or dist.get_world_size() == 1
     joinable = join_tokens > 0 and (one_rank or not hasattr(logprob_model, "unshard"))
+    given = micro_batches
+    if joinable:  # passes are this rank's own business: fillers are not scored (their error is logged under an
+        keep = scored(given)  # all-False mask, their log-probabilities are never used)
+        micro_batches = [given[i] for i in keep]
     rows = join_micro_batches(micro_batches, join_tokens) if joinable else \
         [JoinedRows(mb, [0], [int(mb["input_ids"].shape[1])], mb["loss_mask"]) for mb in micro_batches]
     errors, k = [], 0
@@ -437,6 +468,10 @@ def recompute_logprobs(logprob_model: nn.Module, micro_batches: list[MicroBatch]
             errors.append(torch.exp(piece - micro_batches[k]["logprobs"].to(device)))
             micro_batches[k]["logprobs"] = piece.cpu()
             k += 1
+    if len(micro_batches) != len(given):
+        done = {id(mb): e for mb, e in zip(micro_batches, errors)}
+        errors = [done[id(mb)] if id(mb) in done else torch.ones(mb["logprobs"].shape, dtype=torch.float32, device=device)
+                  for mb in given]
     return errors
 
 

@@ -167,6 +167,42 @@ def test_ragged_rows_of_several_shapes_and_graph_eviction():
         torch.testing.assert_close(m1, m0, rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("join", [0, 16384])
+def test_fillers_left_out_give_the_step_that_runs_them(join):
+    """The orchestrator's filler micro-batches (all-False mask, advantage 0) are not run; statistics, the loss
+    of 0 logged for each, gradient norm and weights are those of the step that runs them."""
+    from prime_rl_cse_amd.optim import FlatAdamW
+
+    gen = torch.Generator().manual_seed(31)
+    loss_cfg = prl.LossConfig()
+    batches = []
+    for _ in range(2):
+        real = rows(gen, 3, [32, 32, 32, 32], 4096)
+        fillers = [copy.deepcopy(real[0]) for _ in range(2)]
+        for f in fillers:
+            f["advantages"] = torch.zeros_like(f["advantages"])
+            f["loss_mask"] = torch.zeros_like(f["loss_mask"])
+        batches.append(real[:2] + fillers[:1] + real[2:] + fillers[1:])
+    results = []
+    for skip in (False, True):
+        cfg = tiny_config(vocab=4096)
+        model = T.get_model(cfg, DEV, torch.float32, seed=11)
+        rep = Replica(model, lambda m: FlatAdamW(m.parameters(), lr=1e-3, weight_decay=0.01))
+        out = []
+        for mbs in batches:
+            res = rep.train_step(copy.deepcopy(mbs), loss_cfg, max_norm=1.0, join_tokens=join, skip_unscored=skip)
+            out.append((res, rep.state.master.detach().clone()))
+        results.append(out)
+    for (r0, m0), (r1, m1) in zip(*results):
+        assert (r0.passes, r1.passes) == ((5, 3) if join == 0 else (1, 1)) and r1.samples == r0.samples == 5
+        assert r1.tokens == 3 * 128 and r0.tokens == 5 * 128
+        assert r1.grad_norm == pytest.approx(r0.grad_norm, rel=1e-6)
+        assert r1.stats.keys() == r0.stats.keys()
+        for k in r0.stats:
+            assert r1.stats[k] == pytest.approx(r0.stats[k], rel=1e-6, abs=1e-8), k
+        torch.testing.assert_close(m1, m0, rtol=1e-6, atol=1e-8)
+
+
 def test_joined_rows_give_the_step_of_the_separate_rows():
     """A step over rows joined end to end (one forward / backward) against the same step row by row: statistics
     (the per-row losses among them), gradient norm and updated weights.  Every token is unmasked here, the first

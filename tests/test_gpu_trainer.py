@@ -41,6 +41,11 @@ def test_train_step_matches_cpu_model_with_oracle_loss(ratio_type):
     gpu_model = copy.deepcopy(cpu_model).to(DEV)
     gen = torch.Generator().manual_seed(5)
     mbs = rows(gen, 3, [20, 12, 32], cfg.vocab_size)
+    # a filler as the orchestrator appends them (batch.py:153-161): the reference runs it, this trainer leaves it
+    # out and logs its loss of 0
+    filler = copy.deepcopy(mbs[0])
+    filler["advantages"], filler["loss_mask"] = torch.zeros_like(filler["advantages"]), torch.zeros_like(filler["loss_mask"])
+    mbs.insert(2, filler)
     loss_cfg = prl.LossConfig(ratio_type=ratio_type, clip_ratio=4.0)
 
     # CPU: reference call order with the oracle
@@ -63,7 +68,8 @@ def test_train_step_matches_cpu_model_with_oracle_loss(ratio_type):
     res = T.train_step(gpu_model, opt, mbs, loss_cfg, max_norm=1e9, device=DEV)
     assert abs(res.grad_norm - cpu_norm) <= 2e-4 * cpu_norm
     assert abs(res.stats["loss/mean"] - sum(cpu_losses) / len(cpu_losses)) <= 1e-4
-    assert res.tokens == 3 * 64
+    assert res.tokens == 3 * 64 and res.samples == 4 and cpu_losses[2] == 0.0
+    assert res.passes == (1 if ratio_type == "token" else 3)
 
     # gradients themselves (recomputed, because train_step clears them)
     for mb in mbs:
@@ -102,6 +108,9 @@ def test_recompute_logprobs_matches_reference_chain():
     gpu_model = copy.deepcopy(cpu_model).to(DEV)
     gen = torch.Generator().manual_seed(9)
     mbs = rows(gen, 2, [16, 24], cfg.vocab_size)
+    filler = copy.deepcopy(mbs[0])  # not scored: keeps its log-probabilities, its (masked) error reads 1
+    filler["loss_mask"] = torch.zeros_like(filler["loss_mask"])
+    kept = filler["logprobs"].clone()
     want_lp, want_err = [], []
     with torch.no_grad():
         for mb in mbs:
@@ -109,8 +118,10 @@ def test_recompute_logprobs_matches_reference_chain():
             lp = O.selective_log_softmax(O.shift_logits(logits) / mb["temperature"], mb["input_ids"])
             want_lp.append(lp)
             want_err.append(torch.exp(lp - mb["logprobs"]))
-    errs = T.recompute_logprobs(gpu_model, mbs, DEV)
-    for mb, lp, err, got in zip(mbs, want_lp, want_err, errs):
+    given = [mbs[0], filler, mbs[1]]
+    errs = T.recompute_logprobs(gpu_model, given, DEV)
+    assert len(errs) == 3 and torch.equal(filler["logprobs"], kept) and torch.equal(errs[1].cpu(), torch.ones_like(kept))
+    for mb, lp, err, got in zip(mbs, want_lp, want_err, [errs[0], errs[2]]):
         assert mb["logprobs"].device.type == "cpu"
         assert torch.allclose(mb["logprobs"], lp, atol=1e-4, rtol=1e-4)
         assert torch.allclose(got.cpu(), err, atol=1e-4, rtol=1e-3)

@@ -44,3 +44,18 @@ def test_rows_with_a_batch_dimension_stay_alone_and_pieces_follow_the_rows():
     out = T.join_per_row(pieces, joined)
     assert [p.shape[1] for p in out] == [4, 8, 11] and out[2][0, 4] == 2.0 and out[2][0, 5] == 3.0
     assert T.join_micro_batches([], 10) == []
+
+
+def test_fillers_are_recognised_by_their_mask_alone():
+    """A filler is a copy of the first micro-batch with an all-False mask (orchestrator/batch.py:153-161); a
+    micro-batch with a single unmasked token is not one; with nothing to score at all, every micro-batch stays."""
+    def mb(mask):
+        t = len(mask)
+        return {"input_ids": torch.zeros(1, t, dtype=torch.int64), "position_ids": torch.arange(t).unsqueeze(0),
+                "advantages": torch.zeros(1, t), "logprobs": torch.zeros(1, t),
+                "loss_mask": torch.tensor([mask], dtype=torch.bool), "temperature": 1.0}
+
+    batch = [mb([True, False, True]), mb([False, False, False]), mb([False, False, True]), mb([False] * 5)]
+    assert T.scored(batch) == [0, 2]
+    assert T.scored([batch[1], batch[3]]) == [0, 1]
+    assert T.scored([]) == []
