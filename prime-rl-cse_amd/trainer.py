@@ -201,6 +201,20 @@ def forward(model: nn.Module, input_ids: Tensor | None, position_ids: Tensor, pl
         return model(position_ids=position_ids, **tokens).logits
 
 
+def plan_scope(plan: Any) -> Any:
+    """`with plan_scope(plan):` keeps `plan` in force for everything inside, backward included.  Activation
+    checkpointing re-runs a block's forward during backward, and the re-run must take the same attention path
+    (and save the same tensors) as the first run did inside `forward`."""
+    import contextlib
+
+    if plan is None:
+        return contextlib.nullcontext()
+    from . import attention
+
+    attention.install()
+    return attention.use_plan(plan)
+
+
 def attention_plan(host_micro_batch: MicroBatch, device: torch.device | str) -> Any:
     """The side-by-side attention layout of one micro-batch, from its position ids while they are still on the
     host (no device synchronisation); None when there is nothing to gain."""
@@ -391,12 +405,14 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, micro_batches
             model.set_requires_gradient_sync(last)
             model.set_reshard_after_backward(last)
         mb = to_device(host_mb, device)
-        logits = forward(model, mb["input_ids"], mb["position_ids"], attention_plan(host_mb, device))
-        vocab = int(logits.shape[-1])
-        loss, aux = policy_loss(logits, mb["input_ids"], mb["position_ids"], mb["advantages"], mb["logprobs"],
-                                mb["loss_mask"], mb["temperature"], loss_config, loss_scale, skip_masked=True)
-        del logits
-        loss.backward(unit_gradient(loss.device))
+        plan = attention_plan(host_mb, device)
+        with plan_scope(plan):  # backward included: checkpointed blocks run their forward again in there
+            logits = forward(model, mb["input_ids"], mb["position_ids"], plan)
+            vocab = int(logits.shape[-1])
+            loss, aux = policy_loss(logits, mb["input_ids"], mb["position_ids"], mb["advantages"], mb["logprobs"],
+                                    mb["loss_mask"], mb["temperature"], loss_config, loss_scale, skip_masked=True)
+            del logits
+            loss.backward(unit_gradient(loss.device))
         if rows is not None:
             losses = restore_row_starts(rows[step_idx], mb, aux, loss_config, vocab, 1.0 / max(float(loss_scale), 1.0))
             mask = rows[step_idx].loss_mask.to(device, non_blocking=True)

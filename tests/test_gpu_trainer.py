@@ -83,6 +83,30 @@ def test_train_step_matches_cpu_model_with_oracle_loss(ratio_type):
         assert torch.allclose(p.grad.cpu(), ref, rtol=2e-3, atol=2e-4 * ref.abs().max().item() + 1e-9), n
 
 
+def test_checkpointed_blocks_take_the_same_attention_path_when_they_run_again():
+    """`[model.ac]` (src/prime_rl/trainer/model.py:195-214): blocks re-run their forward inside backward, where the
+    packed-row attention layout must still be in force; the step is the one of the model without checkpointing."""
+    from torch.distributed.algorithms._checkpoint.checkpoint_wrapper import checkpoint_wrapper
+
+    cfg = tiny_config()
+    gen = torch.Generator().manual_seed(15)
+    mbs = rows(gen, 2, [20, 12, 32], cfg.vocab_size) + rows(gen, 1, [16, 16, 16, 16], cfg.vocab_size)
+    results = []
+    for ac in (False, True):
+        model = T.get_model(cfg, DEV, torch.float32, seed=3)
+        if ac:
+            for name, block in list(model.model.layers.named_children()):
+                model.model.layers.register_module(name, checkpoint_wrapper(block, preserve_rng_state=False))
+        opt = torch.optim.SGD(model.parameters(), lr=0.0)
+        for join in (0, 16384):
+            results.append(T.train_step(model, opt, copy.deepcopy(mbs), prl.LossConfig(), max_norm=1e9, device=DEV,
+                                        join_tokens=join))
+    for plain, checkpointed in zip(results[:2], results[2:]):
+        assert checkpointed.grad_norm == pytest.approx(plain.grad_norm, rel=1e-5)
+        for k in plain.stats:
+            assert checkpointed.stats[k] == pytest.approx(plain.stats[k], rel=1e-5, abs=1e-7), k
+
+
 def test_bf16_model_step_runs_and_learns_direction():
     """bf16 parameters (what FSDP puts on the wire): one SGD step along the
     gradient lowers the loss on the same batch."""
