@@ -252,8 +252,8 @@ def scored(micro_batches: list[MicroBatch]) -> list[int]:
     """Indices of the micro-batches that can change anything: those with at least one unmasked token.
 
     The orchestrator pads every step with filler micro-batches, copies of the first one with advantage 0 and an
-    all-False mask (src/prime_rl/orchestrator/batch.py:153-161: `W - n % W` of them, so a whole extra round when
-    the count already divides), because FSDP's collectives need the same number of passes on every rank.  A
+    all-False mask (src/prime_rl/orchestrator/batch.py:153-161: with W > 1 ranks `W - n % W` of them, so a whole
+    extra round when the count already divides), because FSDP's collectives need the same number of passes on every rank.  A
     micro-batch without an unmasked token has loss 0 and gradient 0, and every logged statistic is taken under the
     mask (src/prime_rl/trainer/rl/train.py:313-333), so where the number of passes is a rank's own business such a
     pass only costs time: the caller runs the others and logs a loss of 0 for each one left out.  The masks are
