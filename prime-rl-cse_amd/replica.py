@@ -172,7 +172,7 @@ class _Captured:
 
 
 _TENSOR_KEYS = ("input_ids", "position_ids", "advantages", "logprobs", "loss_mask")
-_AUX_KEYS = ("logprobs", "entropy", "importance_ratio", "clipped_importance_ratio", "is_clipped")
+_AUX_KEYS = ("logprobs", "entropy", "importance_ratio", "clipped_importance_ratio", "is_clipped", "n_seg")
 
 
 class Replica:
@@ -358,13 +358,13 @@ class Replica:
         same results and the same `StepResult` as `trainer.train_step`, micro-batches joined the same way and
         fillers left out the same way (`trainer.scored`)."""
         from .trainer import (MERGE_MAX_TOKENS, StepResult, attention_plan, join_micro_batches, join_per_row,
-                              local_loss_scale, restore_row_starts, scored)
+                              add_ratio_statistics, local_loss_scale, restore_row_starts, scored)
 
         join_tokens = MERGE_MAX_TOKENS if join_tokens is None else join_tokens
         t0 = time.perf_counter()
         n_given = len(micro_batches)
         inv_scale = 1.0 / max(float(local_loss_scale(micro_batches, loss_config)), 1.0)
-        if skip_unscored:
+        if skip_unscored and loss_config.ratio_type == "token":
             keep = scored(micro_batches)
             micro_batches = [micro_batches[i] for i in keep]
             if recomputed_errors is not None:
@@ -392,9 +392,7 @@ class Replica:
             tensors.add("loss", losses)
             if recomputed_errors is not None:
                 tensors.add("recomputed_logprob_error", recomputed_errors[step_idx], mask)
-            if loss_config.ratio_type == "token":
-                for key in ("importance_ratio", "clipped_importance_ratio", "is_clipped"):
-                    tensors.add(key, aux[key], mask)
+            add_ratio_statistics(tensors, aux, mask, loss_config)
             tokens += int(mb["input_ids"].numel())
         if n_given > len(micro_batches):  # every filler left out: a loss of 0, as the reference logs for it
             tensors.add("loss", torch.zeros(n_given - len(micro_batches), dtype=torch.float32, device=self.device))

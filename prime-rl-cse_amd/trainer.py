@@ -248,6 +248,19 @@ def local_loss_scale(micro_batches: list[MicroBatch], loss_config: LossConfig) -
     return int(micro_batches[0]["input_ids"].shape[0] * len(micro_batches))
 
 
+def add_ratio_statistics(tensors: Tensors, aux: dict[str, Tensor], mask: Tensor, loss_config: LossConfig) -> None:
+    """The three logged tensors of `compute_loss` into `tensors` as the reference selects them
+    (src/prime_rl/trainer/rl/train.py:327-333): per token under the loss mask, or, with one ratio per sample,
+    every sample's value.  `policy_loss` leaves room for T // 2 + 1 samples and fills the first `n_seg`, a count
+    that stays on the device: the selection is made there too."""
+    keys = ("importance_ratio", "clipped_importance_ratio", "is_clipped")
+    if loss_config.ratio_type == "sequence":
+        n = aux[keys[0]].numel()
+        mask = torch.arange(n, device=aux[keys[0]].device) < aux["n_seg"].reshape(())
+    for key in keys:
+        tensors.add(key, aux[key], mask)
+
+
 def scored(micro_batches: list[MicroBatch]) -> list[int]:
     """Indices of the micro-batches that can change anything: those with at least one unmasked token.
 
@@ -370,8 +383,8 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, micro_batches
     `recomputed_logprob_error` (train.py:316-318).  In token mode consecutive
     micro-batches are joined into rows of up to `join_tokens` tokens and run as
     one (`join_micro_batches`; 0 keeps them apart).  Micro-batches without an
-    unmasked token (the orchestrator's fillers) are not run where that is this
-    rank's own business (`scored`; `skip_unscored=False` runs them)."""
+    unmasked token (the orchestrator's fillers) are not run in token mode where
+    that is this rank's own business (`scored`; `skip_unscored=False` runs them)."""
     t0 = time.perf_counter()
     n_given = len(micro_batches)
     loss_scale = local_loss_scale(micro_batches, loss_config)
@@ -384,7 +397,8 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, micro_batches
     one_rank = not dist.is_initialized() or dist.get_world_size() == 1
     passes_are_local = one_rank or getattr(model, "_prl_keep_gathered", False) or not hasattr(model, "unshard")
     left_out = 0
-    if passes_are_local and skip_unscored:
+    # (token mode only: with one ratio per sample the reference logs every sample's ratio unmasked, a filler's too)
+    if passes_are_local and skip_unscored and loss_config.ratio_type == "token":
         keep = scored(micro_batches)
         left_out = len(micro_batches) - len(keep)
         micro_batches = [micro_batches[i] for i in keep]
@@ -424,9 +438,7 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, micro_batches
         tensors.add("loss", losses)
         if recomputed_errors is not None:
             tensors.add("recomputed_logprob_error", recomputed_errors[step_idx], mask)
-        if loss_config.ratio_type == "token":
-            for key in ("importance_ratio", "clipped_importance_ratio", "is_clipped"):
-                tensors.add(key, aux[key], mask)
+        add_ratio_statistics(tensors, aux, mask, loss_config)
         tokens += int(mb["input_ids"].numel())
     if left_out:
         tensors.add("loss", torch.zeros(left_out, dtype=torch.float32, device=device))

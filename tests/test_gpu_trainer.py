@@ -50,17 +50,20 @@ def test_train_step_matches_cpu_model_with_oracle_loss(ratio_type):
 
     # CPU: reference call order with the oracle
     scale = T.local_loss_scale(mbs, loss_cfg)
-    cpu_losses = []
+    cpu_losses, cpu_logged = [], {}
     for mb in mbs:
         logits = T.forward(cpu_model, mb["input_ids"], mb["position_ids"])
         x = O.shift_logits(logits.float().contiguous()) / mb["temperature"]
         lp = O.selective_log_softmax(x, mb["input_ids"])
         lens = O.get_response_lengths(mb["position_ids"])
-        loss, _ = O.compute_loss(lp.squeeze().split(lens), mb["logprobs"].squeeze().split(lens),
-                                 mb["advantages"].squeeze().split(lens), mb["loss_mask"].squeeze().split(lens),
-                                 O.LossConfig(ratio_type, False, 4.0), scale)
+        loss, logged = O.compute_loss(lp.squeeze().split(lens), mb["logprobs"].squeeze().split(lens),
+                                      mb["advantages"].squeeze().split(lens), mb["loss_mask"].squeeze().split(lens),
+                                      O.LossConfig(ratio_type, False, 4.0), scale)
         loss.backward()
         cpu_losses.append(loss.item())
+        for k, v in logged.items():  # src/prime_rl/trainer/rl/train.py:327-333
+            cpu_logged.setdefault(k, []).append(v.detach() if ratio_type == "sequence"
+                                                else v.detach()[mb["loss_mask"].squeeze()])
     cpu_norm = torch.nn.utils.clip_grad_norm_(cpu_model.parameters(), 1e9).item()
     cpu_grads = {n: p.grad.clone() for n, p in cpu_model.named_parameters()}
 
@@ -68,8 +71,13 @@ def test_train_step_matches_cpu_model_with_oracle_loss(ratio_type):
     res = T.train_step(gpu_model, opt, mbs, loss_cfg, max_norm=1e9, device=DEV)
     assert abs(res.grad_norm - cpu_norm) <= 2e-4 * cpu_norm
     assert abs(res.stats["loss/mean"] - sum(cpu_losses) / len(cpu_losses)) <= 1e-4
-    assert res.tokens == 3 * 64 and res.samples == 4 and cpu_losses[2] == 0.0
-    assert res.passes == (1 if ratio_type == "token" else 3)
+    # token mode leaves the filler out; with one ratio per sample the filler's ratios are logged, so it runs
+    assert res.tokens == (3 if ratio_type == "token" else 4) * 64 and res.samples == 4 and cpu_losses[2] == 0.0
+    for k, parts in cpu_logged.items():
+        v = torch.cat([p.float().reshape(-1) for p in parts])
+        assert res.stats[f"{k}/mean"] == pytest.approx(v.mean().item(), rel=1e-4, abs=1e-6), k
+        assert res.stats[f"{k}/max"] == pytest.approx(v.max().item(), rel=1e-4, abs=1e-6), k
+    assert res.passes == (1 if ratio_type == "token" else 4)
 
     # gradients themselves (recomputed, because train_step clears them)
     for mb in mbs:
@@ -234,7 +242,9 @@ def test_trainer_entry_point_on_rollout_files(tmp_path, monkeypatch):
                           loss={"ratio_type": "sequence"})
     history = train(cfg)
     assert len(history) == 2 and history[0]["optim/grad_norm"] > 0
-    assert "importance_ratio/mean" not in history[0]  # per-sample ratios are not logged per token
+    # one ratio per sample, logged for every sample (src/prime_rl/trainer/rl/train.py:327-333)
+    assert 0.0 < history[0]["importance_ratio/min"] <= history[0]["importance_ratio/mean"] < 8.0
+    assert history[0]["is_clipped/max"] in (0.0, 1.0)
     assert (tmp_path / "weights" / "step_2" / "pytorch_model.bin").exists()
 
 
