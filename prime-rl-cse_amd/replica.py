@@ -358,7 +358,8 @@ class Replica:
         same results and the same `StepResult` as `trainer.train_step`, micro-batches joined the same way and
         fillers left out the same way (`trainer.scored`)."""
         from .trainer import (MERGE_MAX_TOKENS, StepResult, attention_plan, join_micro_batches, join_per_row,
-                              add_ratio_statistics, local_loss_scale, restore_row_starts, scored)
+                              add_ratio_statistics, local_loss_scale, ones_as_recomputed_error, restore_row_starts,
+                              scored)
 
         join_tokens = MERGE_MAX_TOKENS if join_tokens is None else join_tokens
         t0 = time.perf_counter()
@@ -400,6 +401,8 @@ class Replica:
         if scheduler is not None:
             scheduler.step()
         stats = tensors.compute_stats()
+        if recomputed_errors is None:
+            ones_as_recomputed_error(stats)
         seconds = time.perf_counter() - t0
         if samples is None:
             samples = n_given

@@ -261,6 +261,14 @@ def add_ratio_statistics(tensors: Tensors, aux: dict[str, Tensor], mask: Tensor,
         tensors.add(key, aux[key], mask)
 
 
+def ones_as_recomputed_error(stats: dict[str, float]) -> None:
+    """Without a log-probability model the reference still logs `recomputed_logprob_error`: of a tensor of ones
+    under the loss mask (src/prime_rl/trainer/rl/train.py:215, 316-318).  Those five numbers need no kernel."""
+    if "probs/mean" in stats:  # at least one unmasked token, as for every other masked key
+        for name, value in (("mean", 1.0), ("median", 1.0), ("std", 0.0), ("min", 1.0), ("max", 1.0)):
+            stats.setdefault(f"recomputed_logprob_error/{name}", value)
+
+
 def scored(micro_batches: list[MicroBatch]) -> list[int]:
     """Indices of the micro-batches that can change anything: those with at least one unmasked token.
 
@@ -450,6 +458,8 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, micro_batches
     if scheduler is not None:
         scheduler.step()
     stats = tensors.compute_stats()
+    if recomputed_errors is None:
+        ones_as_recomputed_error(stats)
     seconds = time.perf_counter() - t0
     if samples is None:
         # a packed row carries as many rollouts as it has position resets; for the

@@ -129,6 +129,8 @@ def test_bf16_model_step_runs_and_learns_direction():
     before = T.train_step(model, opt, mbs, prl.LossConfig(), max_norm=1e9, device=DEV)
     after = T.train_step(model, opt, mbs, prl.LossConfig(), max_norm=1e9, device=DEV)
     assert after.stats["loss/mean"] < before.stats["loss/mean"]
+    # no log-probability model: the reference logs the error of a tensor of ones (train.py:215, 316-318)
+    assert before.stats["recomputed_logprob_error/mean"] == 1.0 and before.stats["recomputed_logprob_error/std"] == 0.0
     assert set(k.split("/")[0] for k in before.stats) >= {"probs", "old_probs", "entropy", "loss", "importance_ratio",
                                                          "clipped_importance_ratio", "is_clipped"}
 
