@@ -211,6 +211,8 @@ def _train(config: RLTrainerConfig, world: Any, device: torch.device, mesh: Any)
             snapshots[step] = {k: v.detach().clone() for k, v in model.state_dict().items()}
         t0 = time.perf_counter()
         loader.wait_for_batch()
+        t_wait = time.perf_counter() - t0
+        t0 = time.perf_counter()
         micro_batches = loader.get_batch()
         t_data = time.perf_counter() - t0
         t_recompute = 0.0
@@ -225,6 +227,7 @@ def _train(config: RLTrainerConfig, world: Any, device: torch.device, mesh: Any)
             t_recompute = time.perf_counter() - t0
         publisher.guard_parameters()
         samples = (config.data.fake.batch_size // world.world_size) if config.data.fake else None
+        lr = optimizer.param_groups[0]["lr"]  # the rate this step is taken with (the scheduler moves on inside)
         if replica is not None:
             res = replica.train_step(micro_batches, config.loss, config.optim.max_norm, scheduler, samples=samples,
                                      recomputed_errors=errors)
@@ -237,11 +240,14 @@ def _train(config: RLTrainerConfig, world: Any, device: torch.device, mesh: Any)
             counter = perf.PerfCounter(model_cfg, seq_len, device_name=device_name, world_size=world.world_size)
         counter.count_tokens(res.tokens * world.world_size)
         step_time = time.perf_counter() - t_step
-        row = {"step": step, "time/step": step_time, "time/forward_backward": res.seconds, "time/load_data": t_data,
+        throughput = counter.get_tokens_per_second() or 0.0
+        row = {"step": step, "time/step": step_time, "time/forward_backward": res.seconds,
+               "time/wait_for_batch": t_wait, "time/load_data": t_data,
                "time/save_weights": t_save, "time/compute_logprobs": t_recompute,
-               "perf/throughput": counter.get_tokens_per_second() or 0.0, "perf/mfu": counter.get_mfu() or 0.0,
+               "perf/throughput": throughput, "perf/throughput_per_gpu": throughput / world.world_size,
+               "perf/mfu": counter.get_mfu() or 0.0,
                "perf/peak_memory": torch.cuda.max_memory_allocated(device) / 1024**3,
-               "optim/lr": optimizer.param_groups[0]["lr"], "optim/grad_norm": res.grad_norm, **res.stats}
+               "optim/lr": lr, "optim/grad_norm": res.grad_norm, **res.stats}
         history.append(row)
         log(f"Step {step} | Time: {step_time:.2f}s | Loss: {res.stats.get('loss/mean', float('nan')):.4f} | "
             f"Entropy: {res.stats.get('entropy/mean', float('nan')):.4f} | "

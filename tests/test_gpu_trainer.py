@@ -178,13 +178,17 @@ def test_trainer_entry_point_on_fake_data(tmp_path, monkeypatch):
 
     _single_rank_env(monkeypatch, 29761)
     toml = tmp_path / "train.toml"
-    toml.write_text("max_steps = 5\nasync_level = 5\n\n[data.fake]\nbatch_size = 8\nmicro_batch_size = 2\nseq_len = 64\n")
+    toml.write_text("max_steps = 5\nasync_level = 5\n\n[data.fake]\nbatch_size = 8\nmicro_batch_size = 2\nseq_len = 64\n"
+                    "\n[scheduler]\ntype = \"linear\"\nwarmup_steps = 2\ndecay_steps = 0\n")
     cfg = parse_argv(RLTrainerConfig, ["@", str(toml), "--bench", "--model.debug.num-layers", "2", "--output-dir",
                                        str(tmp_path / "out"), "--recompute-logprobs"], use_env=False)
     history = train(cfg)
     assert len(history) == 4 and all(h["time/step"] > 0 for h in history)  # bench: 1 warm-up + 3 measured steps
     assert {"loss/mean", "entropy/mean", "importance_ratio/mean", "recomputed_logprob_error/mean", "optim/grad_norm",
-            "perf/throughput"} <= set(history[-1])
+            "perf/throughput", "perf/throughput_per_gpu", "time/wait_for_batch"} <= set(history[-1])
+    # the rate a step was taken with, not the one the scheduler has moved on to (train.py:346-347 of the reference)
+    lrs = [h["optim/lr"] for h in history]
+    assert lrs[0] < lrs[1] < lrs[2] == pytest.approx(1e-6) and lrs[3] == pytest.approx(1e-6)
     for step in (1, 2, 3, 4):
         assert (tmp_path / "out" / "weights" / f"step_{step}" / "pytorch_model.bin").exists()
     assert not list((tmp_path / "out").rglob("*.tmp"))
