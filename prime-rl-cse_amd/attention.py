@@ -29,6 +29,8 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor
 
+from .batch import host_to_device
+
 
 @dataclass
 class PackedPlan:
@@ -65,7 +67,7 @@ def plan_from_position_ids(position_ids: Tensor, device: torch.device | str, max
         return None
     lengths = np.diff(np.concatenate([starts, [total]]))
     lmax = int(lengths.max())
-    cu = torch.from_numpy(np.concatenate([starts, [total]]).astype(np.int32)).to(device, non_blocking=True)
+    cu = host_to_device(torch.from_numpy(np.concatenate([starts, [total]]).astype(np.int32)), device)
     side_by_side = n >= 2 and n * lmax * lmax <= max_work_ratio * total * total
     if not side_by_side:
         return PackedPlan(total, n, lmax, False, None, None, cu, False)
@@ -75,8 +77,8 @@ def plan_from_position_ids(position_ids: Tensor, device: torch.device | str, max
     gather = starts[:, None] + np.minimum(offs, lengths[:, None] - 1)  # padding repeats the sample's last token
     seg = np.repeat(np.arange(n, dtype=np.int64), lengths)
     scatter = seg * lmax + (np.arange(total, dtype=np.int64) - starts[seg])
-    g = torch.from_numpy(gather.reshape(-1)).to(device, non_blocking=True)
-    sc = torch.from_numpy(scatter).to(device, non_blocking=True)
+    g = host_to_device(torch.from_numpy(gather.reshape(-1)), device)
+    sc = host_to_device(torch.from_numpy(scatter), device)
     return PackedPlan(total, n, lmax, False, g, sc, cu)
 
 

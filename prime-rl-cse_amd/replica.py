@@ -40,7 +40,7 @@ import torch.distributed as dist
 from torch import Tensor, nn
 
 from . import _capi as C
-from .batch import to_device
+from .batch import host_to_device, to_device
 from .config import LossConfig
 from .data import MicroBatch
 from .loss import policy_loss, unit_gradient
@@ -273,7 +273,7 @@ class Replica:
         ptrs = [grad.data_ptr() if p is table.weight else 0 for p in self.state.params]
         if not any(ptrs):
             raise RuntimeError("Replica: the embedding table is not among the model's parameters")
-        self._accumulate(torch.tensor(ptrs, dtype=torch.int64).to(self.device))
+        self._accumulate(host_to_device(ptrs, self.device, torch.int64))
 
     def _drop_grads(self) -> None:
         for p in self.state.params:
@@ -340,7 +340,7 @@ class Replica:
             self.replays += 1
             return cap.loss.clone(), {k: cap.aux[k].clone() for k in _AUX_KEYS}
         loss, aux, grads, embed_grad = self._forward_backward(mb, plan, loss_config)
-        src = torch.tensor(self._grad_pointers(grads), dtype=torch.int64).to(self.device)
+        src = host_to_device(self._grad_pointers(grads), self.device, torch.int64)
         self._accumulate(src)
         self._embedding_backward(mb["input_ids"], embed_grad)
         del grads, embed_grad
@@ -384,7 +384,7 @@ class Replica:
             loss, aux = self.micro_batch(mb, attention_plan(host_mb, self.device), loss_config)
             if rows is not None:
                 losses = restore_row_starts(rows[step_idx], mb, aux, loss_config, vocab, inv_scale)
-                mask = rows[step_idx].loss_mask.to(self.device, non_blocking=True)
+                mask = host_to_device(rows[step_idx].loss_mask, self.device)
             else:
                 losses, mask = (loss * inv_scale).reshape(1), mb["loss_mask"]
             tensors.add("probs", aux["logprobs"], mask, exp=True)

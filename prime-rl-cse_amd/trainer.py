@@ -22,7 +22,7 @@ import torch
 import torch.distributed as dist
 from torch import Tensor, nn
 
-from .batch import to_device
+from .batch import host_to_device, to_device
 from .config import LossConfig
 from .data import MicroBatch
 from .loss import policy_loss, unit_gradient
@@ -361,9 +361,9 @@ def restore_row_starts(rows: JoinedRows, mb: dict[str, Any], aux: dict[str, Tens
     place).  Returns the losses of the original rows [n_rows], each under the step's normaliser `1 / inv_scale`
     (what the reference logs as one `loss` per micro-batch)."""
     dev = aux["logprobs"].device
-    mask = rows.loss_mask.to(dev, non_blocking=True).reshape(-1)
+    mask = host_to_device(rows.loss_mask, dev).reshape(-1)
     if len(rows.starts) > 1:
-        idx = torch.tensor(rows.starts[1:], dtype=torch.int64).to(dev, non_blocking=True)
+        idx = host_to_device(rows.starts[1:], dev, torch.int64)
         ln_v = float(torch.log(torch.tensor(float(vocab), dtype=torch.float32)))
         old = mb["logprobs"].reshape(-1)[idx].float()
         ratio = torch.exp(-ln_v - old)
@@ -437,7 +437,7 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, micro_batches
             loss.backward(unit_gradient(loss.device))
         if rows is not None:
             losses = restore_row_starts(rows[step_idx], mb, aux, loss_config, vocab, 1.0 / max(float(loss_scale), 1.0))
-            mask = rows[step_idx].loss_mask.to(device, non_blocking=True)
+            mask = host_to_device(rows[step_idx].loss_mask, device)
         else:
             losses, mask = loss.detach().reshape(1), mb["loss_mask"]
         tensors.add("probs", aux["logprobs"], mask, exp=True)
@@ -494,16 +494,16 @@ def recompute_logprobs(logprob_model: nn.Module, micro_batches: list[MicroBatch]
     errors, k = [], 0
     for r in rows:
         mb = r.micro_batch
-        ids = mb["input_ids"].to(device)
-        logits = forward(logprob_model, ids, mb["position_ids"].to(device), attention_plan(mb, device))
+        ids = host_to_device(mb["input_ids"], device)
+        logits = forward(logprob_model, ids, host_to_device(mb["position_ids"], device), attention_plan(mb, device))
         lp = selective_log_softmax(shift_logits(logits) / mb["temperature"], ids)
         del logits
         if len(r.starts) > 1:
-            idx = torch.tensor(r.starts[1:], dtype=torch.int64).to(device, non_blocking=True)
+            idx = host_to_device(r.starts[1:], device, torch.int64)
             lp[:, idx] = -float(torch.log(torch.tensor(float(logprob_model.config.vocab_size), dtype=torch.float32)))
         for a, n in zip(r.starts, r.lengths):  # back to the micro-batches the caller holds
             piece = lp[:, a : a + n]
-            errors.append(torch.exp(piece - micro_batches[k]["logprobs"].to(device)))
+            errors.append(torch.exp(piece - host_to_device(micro_batches[k]["logprobs"], device)))
             micro_batches[k]["logprobs"] = piece.cpu()
             k += 1
     if len(micro_batches) != len(given):

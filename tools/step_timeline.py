@@ -25,6 +25,16 @@ def main() -> None:
         busy += e - s
         prev_end = max(prev_end, e)
     print(f"span {(prev_end - t0) / 1e3:.1f} us, kernels busy {busy / 1e3:.1f} us")
+    # the largest idle gaps, with the kernels on either side
+    gaps, end = [], rows[0][1]
+    for (s0, e0, n0), (s1, e1, n1) in zip(rows, rows[1:]):
+        end = max(end, e0)
+        gaps.append((s1 - end, n0.split("(")[0][-50:], n1.split("(")[0][-50:], (s1 - t0) / 1e3))
+    total = sum(g[0] for g in gaps if g[0] > 0)
+    print(f"idle in gaps {total / 1e3:.1f} us; gaps over 15 us:")
+    for g in sorted(gaps, reverse=True)[:25]:
+        if g[0] > 15000:
+            print(f"  {g[0] / 1e3:8.1f} us at {g[3]:10.1f}: {g[1]}  ->  {g[2]}")
 
 
 if __name__ == "__main__":
