@@ -217,6 +217,37 @@ def use_plan(plan: PackedPlan | None):
         _ACTIVE[0] = prev
 
 
+def maskless(plan: PackedPlan | None, model: Any) -> bool:
+    """Whether a forward of `model` under `plan` never looks at the attention mask, so that the model need not
+    build one: transformers makes a [T, T] boolean mask per forward (two passes over 268 MB at 16 K tokens, 0.4 ms)
+    that every path below except the masked row ignores.  True only where all layers are plain causal attention
+    through the registered "sdpa" function, without dropout, and either the plan lays the samples side by side
+    (then the short-sample kernels, `varlen_attn` or the padded layout take every layer) or the model computes in
+    a half-precision type that `varlen_attn` takes (then that does, whatever the samples' lengths).  Such a
+    forward passes `attention_mask={"full_attention": None}`; a layer that turns out to need the mask after all
+    raises."""
+    cfg = getattr(model, "config", None)
+    kinds = getattr(cfg, "layer_types", None)
+    if not (plan is not None and _HF_SDPA and kinds and all(k == "full_attention" for k in kinds)
+            and getattr(cfg, "_attn_implementation", None) == "sdpa"
+            and not float(getattr(cfg, "attention_dropout", 0.0) or 0.0)):
+        return False
+    if plan.side_by_side:
+        return True
+    first = next(iter(model.parameters()), None)
+    return bool(first is not None and first.is_cuda and first.dtype in (torch.bfloat16, torch.float16)
+                and plan.cu is not None and _varlen_attn() is not None)
+
+
+def _masked_row(module: Any, query: Tensor, key: Tensor, value: Tensor, attention_mask: Tensor | None, plan: Any,
+                **kwargs: Any):
+    """transformers' own attention over the whole row under its block-diagonal mask."""
+    if attention_mask is None and plan is not None and plan.n > 1:
+        raise RuntimeError("packed-row attention: this layer needs the block-diagonal mask, which was not built "
+                           "(attention.maskless said no layer would)")
+    return _HF_SDPA[0](module, query, key, value, attention_mask, **kwargs)
+
+
 def packed_sdpa_attention(module: Any, query: Tensor, key: Tensor, value: Tensor, attention_mask: Tensor | None,
                           dropout: float = 0.0, scaling: float | None = None, **kwargs: Any):
     """Drop-in for transformers' `sdpa_attention_forward` (same arguments, same [batch, seq, heads, dim] result).
@@ -225,13 +256,15 @@ def packed_sdpa_attention(module: Any, query: Tensor, key: Tensor, value: Tensor
     windowed = kwargs.get("sliding_window") is not None  # a sliding-window layer needs its own mask: not ours
     if plan is None or windowed or query.shape[0] != 1 or query.shape[2] != plan.total \
             or key.shape[2] != plan.total or dropout:
-        return _HF_SDPA[0](module, query, key, value, attention_mask, dropout=dropout, scaling=scaling, **kwargs)
+        return _masked_row(module, query, key, value, attention_mask, plan, dropout=dropout, scaling=scaling,
+                           **kwargs)
     if short_attention_supported(query, key, plan):
         return short_attention(query, key, value, plan, scaling), None
     if varlen_attention_supported(query, plan, scaling):
         return varlen_attention(query, key, value, plan), None
     if not plan.side_by_side:
-        return _HF_SDPA[0](module, query, key, value, attention_mask, dropout=dropout, scaling=scaling, **kwargs)
+        return _masked_row(module, query, key, value, attention_mask, plan, dropout=dropout, scaling=scaling,
+                           **kwargs)
     n, lmax = plan.n, plan.lmax
     gqa = key.shape[1] != query.shape[1]
 

@@ -198,7 +198,16 @@ def forward(model: nn.Module, input_ids: Tensor | None, position_ids: Tensor, pl
 
     attention.install()
     with attention.use_plan(plan):
+        if _maskless_enabled() and attention.maskless(plan, model):  # no [T, T] mask to build: nothing reads it
+            tokens["attention_mask"] = {"full_attention": None}
         return model(position_ids=position_ids, **tokens).logits
+
+
+def _maskless_enabled() -> bool:
+    """PRL_ATTN_MASKLESS=0 lets transformers build its mask for every forward (for A/B measurements)."""
+    import os
+
+    return os.environ.get("PRL_ATTN_MASKLESS", "1") != "0"
 
 
 def plan_scope(plan: Any) -> Any:

@@ -139,3 +139,44 @@ def test_model_with_short_attention_matches_the_masked_row(lengths, monkeypatch)
     for n, p in model.named_parameters():
         a, b = p.grad.float(), grads[n].float()
         assert (a - b).norm().item() <= 0.03 * b.norm().item() + 1e-6, n
+
+
+def test_forward_without_a_mask_is_the_forward_with_one(monkeypatch):
+    """Rows whose samples are laid side by side never read transformers' [T, T] mask, so `trainer.forward` tells
+    the model not to build it; the logits are bit for bit those of the same kernels with the mask built.  A row
+    of one sample keeps its mask (the masked-row path may read it), and so does a model without the mapping."""
+    from prime_rl_cse_amd import trainer as T
+
+    cfg = T.model_config("Qwen/Qwen3-0.6B", num_layers=2)
+    model = T.get_model(cfg, DEV, torch.bfloat16, seed=2)
+    lengths = [50, 7, 31, 64, 2, 40, 60, 33, 48, 21, 128]
+    t = sum(lengths)
+    ids = torch.randint(0, 1000, (1, t), generator=torch.Generator().manual_seed(1)).to(DEV)
+    pos = torch.cat([torch.arange(n) for n in lengths])[None]
+    plan = attention.plan_from_position_ids(pos, DEV)
+    attention.install()
+    assert not plan.side_by_side and attention.maskless(plan, model)  # bf16: varlen_attn takes any row
+    wide = attention.plan_from_position_ids(torch.cat([torch.arange(16)] * 8)[None], DEV)
+    single = attention.plan_from_position_ids(torch.arange(90)[None], DEV)
+    fp32 = T.get_model(T.model_config("Qwen/Qwen3-0.6B", num_layers=1, hidden_size=64, intermediate_size=128,
+                                      num_attention_heads=4, num_key_value_heads=2, head_dim=16, vocab_size=512),
+                       DEV, torch.float32, seed=1)
+    assert wide.side_by_side and attention.maskless(wide, fp32)
+    assert not attention.maskless(single, fp32) and not attention.maskless(plan, fp32)
+    assert not attention.maskless(None, model)
+    built = []
+    import transformers.models.qwen3.modeling_qwen3 as Q
+
+    real = Q.create_causal_mask
+    monkeypatch.setattr(Q, "create_causal_mask", lambda **kw: (built.append(1), real(**kw))[1])
+    with torch.no_grad():
+        got = T.forward(model, ids, pos.to(DEV), plan)
+        assert not built
+        with attention.use_plan(plan):
+            want = model(input_ids=ids, position_ids=pos.to(DEV)).logits
+        assert built == [1]
+    assert torch.equal(got, want)
+    # a layer that needs the mask after all says so instead of attending across samples
+    q = torch.randn(1, 16, t, 128, device=DEV, dtype=torch.bfloat16)
+    with attention.use_plan(plan), pytest.raises(RuntimeError, match="mask"):
+        attention.packed_sdpa_attention(None, q, q[:, :8], q[:, :8], None, dropout=0.1)
