@@ -269,3 +269,65 @@ def test_eligibility():
     assert eligible(model, "adamw") is None and eligible(model, "sgd") is None
     assert "element-wise" in eligible(model, "muon")
     assert "checkpointing" in eligible(model, "adamw", activation_checkpointing=True)
+
+
+def _replica_rank(rank, world, port, q, seed):
+    """One of two ranks that share the GPU and exchange over gloo (through host memory): a step of `Replica` on
+    this rank's own micro-batches."""
+    import os
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", LOCAL_WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    from prime_rl_cse_amd.world import reset_world
+
+    reset_world()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        gen = torch.Generator().manual_seed(seed + rank)
+        mbs = rows(gen, 2 + rank, [24, 8, 32], 4096)  # the ranks hold different numbers of rows and of tokens
+        model = T.get_model(tiny_config(vocab=4096), DEV, torch.float32, seed=11)
+        rep = Replica(model, lambda m: torch.optim.SGD(m.parameters(), lr=1.0), compute_dtype=torch.float32)
+        before = rep.state.flat16.clone()
+        res = rep.train_step(mbs, prl.LossConfig(), max_norm=1e9)
+        q.put((rank, (before - rep.state.flat16).cpu(), res.grad_norm, res.stats["loss/mean"], res.stats["entropy/mean"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_take_the_mean_of_their_own_steps():
+    """Data parallel over two ranks (gloo, sharing the one GPU): every rank normalises its loss by its OWN unmasked
+    tokens (src/prime_rl/trainer/rl/train.py:263-267), the gradients are averaged over the ranks, each rank updates
+    its shard of the master weights and all ranks end with the same whole model.  With SGD at rate 1 the step IS the
+    gradient: it must be the mean of the two steps each rank's data gives on a single rank."""
+    import torch.multiprocessing as mp
+
+    seed = 77
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_replica_rank, args=(r, 2, 29741, q, seed)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    alone, losses = [], []
+    for rank in range(2):
+        gen = torch.Generator().manual_seed(seed + rank)
+        mbs = rows(gen, 2 + rank, [24, 8, 32], 4096)
+        model = T.get_model(tiny_config(vocab=4096), DEV, torch.float32, seed=11)
+        rep = Replica(model, lambda m: torch.optim.SGD(m.parameters(), lr=1.0), compute_dtype=torch.float32)
+        before = rep.state.flat16.clone()
+        res = rep.train_step(mbs, prl.LossConfig(), max_norm=1e9)
+        alone.append((before - rep.state.flat16).cpu())
+        losses += [res.stats["loss/mean"]] * (2 + rank)
+    want = 0.5 * (alone[0] + alone[1])
+    n = want.numel()
+    for rank, step, norm, loss, entropy in results:
+        # steps read off as differences of fp32 weights: absolute accuracy is an ulp of a weight, not of a step
+        torch.testing.assert_close(step[:n], want, rtol=1e-4, atol=1e-5 * want.abs().max().item())
+        assert norm == pytest.approx(want.norm().item(), rel=1e-4)
+        assert loss == pytest.approx(sum(losses) / len(losses), rel=1e-4, abs=1e-7)  # mean over both ranks' rows
+    assert torch.equal(results[0][1], results[1][1]) and results[0][4] == results[1][4]
