@@ -394,7 +394,7 @@ class Replica:
             if recomputed_errors is not None:
                 tensors.add("recomputed_logprob_error", recomputed_errors[step_idx], mask)
             add_ratio_statistics(tensors, aux, mask, loss_config)
-            tokens += int(mb["input_ids"].numel())
+            tokens += int(mb["input_ids"].numel()) - (rows[step_idx].padding if rows is not None else 0)
         if n_given > len(micro_batches):  # every filler left out: a loss of 0, as the reference logs for it
             tensors.add("loss", torch.zeros(n_given - len(micro_batches), dtype=torch.float32, device=self.device))
         grad_norm = self.state.finish_step(self.optimizer, max_norm)

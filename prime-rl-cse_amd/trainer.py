@@ -303,9 +303,34 @@ class JoinedRows:
     starts: list[int]  # first token of every original row
     lengths: list[int]
     loss_mask: Tensor  # the original masks, joined ([1, T], host)
+    padding: int = 0  # unscored tokens appended after the last row (the joined row's length is rounded up)
 
 
-def join_micro_batches(micro_batches: list[MicroBatch], max_tokens: int = MERGE_MAX_TOKENS) -> list[JoinedRows]:
+PAD_TOKENS = 512  # joined rows are rounded up to a multiple of this many tokens
+
+
+def _pad_tokens() -> int:
+    """PRL_PAD_TOKENS overrides the rounding of joined rows (0: none)."""
+    import os
+
+    try:
+        return max(0, int(os.environ.get("PRL_PAD_TOKENS", PAD_TOKENS)))
+    except ValueError:
+        return PAD_TOKENS
+
+
+def _padding(n: int, like: MicroBatch) -> MicroBatch:
+    """`n` tokens nobody scores, as samples of at most 64 tokens (short enough for every attention path): mask
+    False, advantage 0.  They follow the last real row, so every real token keeps its place."""
+    return {"input_ids": torch.zeros(1, n, dtype=like["input_ids"].dtype),
+            "position_ids": (torch.arange(n, dtype=like["position_ids"].dtype) % 64).unsqueeze(0),
+            "advantages": torch.zeros(1, n, dtype=like["advantages"].dtype),
+            "logprobs": torch.zeros(1, n, dtype=like["logprobs"].dtype),
+            "loss_mask": torch.zeros(1, n, dtype=torch.bool)}
+
+
+def join_micro_batches(micro_batches: list[MicroBatch], max_tokens: int = MERGE_MAX_TOKENS,
+                       pad_to: int | None = None) -> list[JoinedRows]:
     """Consecutive micro-batches with the same temperature joined into rows of at most `max_tokens` tokens.
 
     The reference runs one forward / backward per micro-batch because of memory (gradient accumulation,
@@ -317,6 +342,7 @@ def join_micro_batches(micro_batches: list[MicroBatch], max_tokens: int = MERGE_
     previous row's last logits.  Those tokens are masked out here and put back by `restore_row_starts`."""
     out: list[JoinedRows] = []
     group: list[MicroBatch] = []
+    pad_to = _pad_tokens() if pad_to is None else pad_to
 
     def flush() -> None:
         if not group:
@@ -325,14 +351,24 @@ def join_micro_batches(micro_batches: list[MicroBatch], max_tokens: int = MERGE_
         starts = [0]
         for n in lengths[:-1]:
             starts.append(starts[-1] + n)
-        joined = {k: torch.cat([mb[k] for mb in group], dim=1) for k in
+        # Rows of real rollouts never have the same length twice, and every new length costs the GEMM library a
+        # kernel selection per product and the allocator fresh blocks: the joined row is rounded up with tokens
+        # nobody scores, so that a run sees a handful of lengths instead of a new one per step.
+        pieces = list(group)
+        total = sum(lengths)
+        pad = (-total) % pad_to if pad_to > 0 and all(mb["input_ids"].shape[0] == 1 for mb in group) else 0
+        if pad and total + pad > max_tokens:
+            pad = 0
+        if pad:
+            pieces.append(_padding(pad, group[0]))
+        joined = {k: torch.cat([mb[k] for mb in pieces], dim=1) for k in
                   ("input_ids", "position_ids", "advantages", "logprobs", "loss_mask")}
         joined["temperature"] = group[0]["temperature"]
         original = joined["loss_mask"]
         if len(group) > 1:
             joined["loss_mask"] = original.clone()
             joined["loss_mask"][0, starts[1:]] = False
-        out.append(JoinedRows(joined, starts, lengths, original))
+        out.append(JoinedRows(joined, starts, lengths, original, pad))
         group.clear()
 
     tokens = 0
@@ -357,7 +393,10 @@ def join_per_row(pieces: list[Tensor], rows: list[JoinedRows]) -> list[Tensor]:
     out, a = [], 0
     for r in rows:
         k = len(r.lengths)
-        out.append(pieces[a] if k == 1 else torch.cat(pieces[a : a + k], dim=1))
+        parts = list(pieces[a : a + k])
+        if r.padding:
+            parts.append(torch.ones((1, r.padding), dtype=parts[0].dtype, device=parts[0].device))
+        out.append(parts[0] if len(parts) == 1 else torch.cat(parts, dim=1))
         a += k
     return out
 
@@ -456,7 +495,7 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, micro_batches
         if recomputed_errors is not None:
             tensors.add("recomputed_logprob_error", recomputed_errors[step_idx], mask)
         add_ratio_statistics(tensors, aux, mask, loss_config)
-        tokens += int(mb["input_ids"].numel())
+        tokens += int(mb["input_ids"].numel()) - (rows[step_idx].padding if rows is not None else 0)
     if left_out:
         tensors.add("loss", torch.zeros(left_out, dtype=torch.float32, device=device))
     grad_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=max_norm)

@@ -59,3 +59,30 @@ def test_fillers_are_recognised_by_their_mask_alone():
     assert T.scored(batch) == [0, 2]
     assert T.scored([batch[1], batch[3]]) == [0, 1]
     assert T.scored([]) == []
+
+
+def test_joined_rows_are_rounded_up_with_tokens_nobody_scores():
+    def mb(n, seed):
+        g = torch.Generator().manual_seed(seed)
+        return {"input_ids": torch.randint(0, 100, (1, n), generator=g), "position_ids": torch.arange(n).unsqueeze(0),
+                "advantages": torch.randn(1, n, generator=g), "logprobs": torch.randn(1, n, generator=g),
+                "loss_mask": torch.rand(1, n, generator=g) < 0.5, "temperature": 1.0}
+
+    batch = [mb(300, 1), mb(211, 2)]
+    (row,) = T.join_micro_batches(batch, 16384, pad_to=512)
+    assert row.padding == 1 and row.micro_batch["input_ids"].shape == (1, 512) and row.lengths == [300, 211]
+    (row,) = T.join_micro_batches(batch, 16384, pad_to=384)
+    t = row.micro_batch["input_ids"].shape[1]
+    assert t == 768 and row.padding == 257 and row.loss_mask.shape == (1, 768)
+    assert not row.micro_batch["loss_mask"][0, 511:].any() and not row.loss_mask[0, 511:].any()
+    assert (row.micro_batch["advantages"][0, 511:] == 0).all()
+    pos = row.micro_batch["position_ids"][0, 511:]
+    assert pos[0] == 0 and int(pos.max()) == 63  # its own samples, short ones
+    assert torch.equal(row.micro_batch["input_ids"][0, :511], torch.cat([b["input_ids"][0] for b in batch]))
+    # per-row pieces follow
+    (piece,) = T.join_per_row([torch.zeros(1, 300), torch.zeros(1, 211)], [row])
+    assert piece.shape == (1, 768)
+    # no room, no rounding; a multiple already, nothing added; 0 switches it off
+    assert T.join_micro_batches(batch, 600, pad_to=512)[0].padding == 0
+    assert T.join_micro_batches([mb(512, 3)], 16384, pad_to=512)[0].padding == 0
+    assert T.join_micro_batches(batch, 16384, pad_to=0)[0].padding == 0
