@@ -83,6 +83,6 @@ def test_joined_rows_are_rounded_up_with_tokens_nobody_scores():
     (piece,) = T.join_per_row([torch.zeros(1, 300), torch.zeros(1, 211)], [row])
     assert piece.shape == (1, 768)
     # no room, no rounding; a multiple already, nothing added; 0 switches it off
-    assert T.join_micro_batches(batch, 600, pad_to=512)[0].padding == 0
+    assert T.join_micro_batches(batch, 511, pad_to=512)[0].padding == 0
     assert T.join_micro_batches([mb(512, 3)], 16384, pad_to=512)[0].padding == 0
     assert T.join_micro_batches(batch, 16384, pad_to=0)[0].padding == 0
