@@ -14,6 +14,9 @@ host with a blocking copy, runs a barrier, and only then lets the step go on
                travel), overlapping the next step's forward and backward.
   3. COPY-OUT  rank 0 copies the gathered tensors into pinned host memory with
                asynchronous copies on the side stream and records an event.
+               (Tensors that are whole on this GPU skip 2 and share ONE staging
+               buffer on the device and one in pinned memory: one multi-tensor
+               copy, one transfer.)
   4. WRITE     a host thread waits for that event, writes `pytorch_model.tmp`
                with torch.save and renames it to `pytorch_model.bin`
                (`weights.py:169-174`): the file layout, the atomic rename and the
@@ -73,6 +76,7 @@ class PendingPublication:
         self.step, self.path = step, path
         self.snapshot_done: Any = None  # event: local shards copied, parameters may change again
         self._thread: threading.Thread | None = None
+        self._slot: Tensor | None = None  # the pinned staging buffer this publication writes from
         self.error: BaseException | None = None
 
     def wait(self, timeout: float | None = None) -> Path:
@@ -84,6 +88,13 @@ class PendingPublication:
         if self.error is not None:
             raise self.error
         return self.path
+
+
+def _flat_staging_enabled() -> bool:
+    """PRL_PUBLISH_FLAT=0 keeps the per-tensor copies for whole tensors too (for A/B measurements)."""
+    import os
+
+    return os.environ.get("PRL_PUBLISH_FLAT", "1") != "0"
 
 
 class WeightPublisher:
@@ -103,6 +114,7 @@ class WeightPublisher:
         self._stream: Any = None
         self._subscribers: list[Callable[[dict[str, Tensor], int], None]] = []
         self._pending: list[PendingPublication] = []
+        self._slots: list[Tensor] = []  # pinned staging buffers of the whole-tensor path
 
     # ------------------------------------------------------------------ plumbing
 
@@ -116,6 +128,43 @@ class WeightPublisher:
         if self._stream is None:
             self._stream = torch.cuda.Stream(device=self.device)  # default priority on purpose
         return self._stream
+
+    @staticmethod
+    def _layout(state: dict[str, Tensor], dtype: torch.dtype) -> tuple[list[tuple], int]:
+        """(name, shape, offset, elements) of every tensor in one staging buffer of `dtype`, slices 256-byte
+        aligned; tensors that share their memory (tied embeddings) share their slice, so the file keeps them tied
+        as `torch.save` of the model's own state dict would.  One element type per buffer: `torch.save` refuses
+        tensors that view one storage as different types."""
+        unit = max(1, 256 // torch.empty((), dtype=dtype).element_size())
+        layout, off, seen = [], 0, {}
+        for name, v in state.items():
+            n = v.numel()
+            key = (v.data_ptr(), tuple(v.shape), tuple(v.stride()), v.dtype)
+            if key in seen and n:
+                layout.append((name, tuple(v.shape), seen[key], n))
+                continue
+            seen[key] = off
+            layout.append((name, tuple(v.shape), off, n))
+            off += (n + unit - 1) // unit * unit
+        return layout, max(off, 1)
+
+    @staticmethod
+    def _views(buffer: Tensor, layout: list[tuple]) -> dict[str, Tensor]:
+        return {name: buffer[off : off + n].view(shape) for name, shape, off, n in layout}
+
+    def _host_slot(self, total: int, dtype: torch.dtype) -> Tensor:
+        """A pinned buffer of `total` elements that no publication in flight is using (at most `max_in_flight`
+        are, and `publish` has waited for the oldest): buffers are kept and reused, pinning memory costs more
+        than the copy."""
+        busy = {id(p._slot) for p in self._pending if p._slot is not None and p._thread is not None
+                and p._thread.is_alive()}
+        fits = lambda b: b.numel() == total and b.dtype == dtype
+        for buf in self._slots:
+            if id(buf) not in busy and fits(buf):
+                return buf
+        buf = torch.zeros(total, dtype=dtype, pin_memory=True)  # zeros: the padding between slices is written too
+        self._slots = [b for b in self._slots if id(b) in busy or fits(b)] + [buf]
+        return buf
 
     # ------------------------------------------------------------------ publication
 
@@ -134,35 +183,69 @@ class WeightPublisher:
         ctx = torch.cuda.stream(side) if side is not None else contextlib.nullcontext()
         if side is not None:
             side.wait_stream(torch.cuda.current_stream(self.device))  # after the optimizer step
+        whole = side is not None and all(v.is_cuda and not isinstance(v, DTensor) for v in state.values()) \
+            and any(v.is_floating_point() for v in state.values()) and _flat_staging_enabled()
         with ctx, torch.no_grad():
-            # 1. snapshot: bf16 copies of the local shards
-            # (always a copy: parameters that already are in `dtype`, as the whole-model trainer's bf16 ones, would
-            # otherwise be read by the copy-out while the next optimizer step rewrites them)
-            snap = {k: (v.detach().to(dtype, copy=True) if v.is_floating_point() else v.detach().clone())
-                    for k, v in state.items()}
-            if side is not None:
-                pending.snapshot_done = torch.cuda.Event()
-                pending.snapshot_done.record(side)
-            # 2. gather (after the downcast: half the bytes on the wire)
-            full: dict[str, Tensor] = {}
-            for k, v in snap.items():
-                full[k] = v.full_tensor() if isinstance(v, DTensor) else v
-            for fn in self._subscribers:
-                fn(full, step)
-            # 3. copy-out on rank 0
             host: dict[str, Tensor] = {}
             copied = None
-            if self._is_master:
-                for k, v in full.items():
-                    if v.device.type == "cuda":
+            if whole:
+                # Whole tensors on this GPU (the whole-model trainer, or one rank): ONE staging buffer on the
+                # device and ONE in pinned host memory, every tensor a 256-byte-aligned slice of them.  The
+                # snapshot is a multi-tensor copy, the copy-out a single transfer, and the host does a handful
+                # of calls instead of three per tensor (21 ms per publication for the 311 tensors of a 0.6B model).
+                floating = {k: v for k, v in state.items() if v.is_floating_point()}
+                others = {k: v.detach().clone() for k, v in state.items() if not v.is_floating_point()}
+                layout, total = self._layout(floating, dtype)
+                flat = torch.empty(total, dtype=dtype, device=self.device)
+                staged = self._views(flat, layout)
+                first = {}  # one copy per slice: tied tensors share theirs
+                for name, _, off, _ in layout:
+                    first.setdefault(off, name)
+                torch._foreach_copy_([staged[k] for k in first.values()], [floating[k].detach() for k in first.values()])
+                full = {k: (staged[k] if k in staged else others[k]) for k in state}  # the state dict's own order
+                pending.snapshot_done = torch.cuda.Event()
+                pending.snapshot_done.record(side)
+                for fn in self._subscribers:
+                    fn(full, step)
+                if self._is_master:
+                    slot = self._host_slot(total, dtype)
+                    slot.copy_(flat, non_blocking=True)
+                    on_host = self._views(slot, layout)
+                    for k, v in others.items():  # the odd integer buffer: a tensor of its own
                         buf = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
                         buf.copy_(v, non_blocking=True)
-                        host[k] = buf
-                    else:
-                        host[k] = v
-                if side is not None:
+                        on_host[k] = buf
+                    host = {k: on_host[k] for k in state}
                     copied = torch.cuda.Event()
                     copied.record(side)
+                    pending._slot = slot
+            else:
+                # 1. snapshot: bf16 copies of the local shards
+                # (always a copy: parameters that already are in `dtype` would otherwise be read by the copy-out
+                # while the next optimizer step rewrites them)
+                snap = {k: (v.detach().to(dtype, copy=True) if v.is_floating_point() else v.detach().clone())
+                        for k, v in state.items()}
+                if side is not None:
+                    pending.snapshot_done = torch.cuda.Event()
+                    pending.snapshot_done.record(side)
+                # 2. gather (after the downcast: half the bytes on the wire)
+                full = {}
+                for k, v in snap.items():
+                    full[k] = v.full_tensor() if isinstance(v, DTensor) else v
+                for fn in self._subscribers:
+                    fn(full, step)
+                # 3. copy-out on rank 0
+                if self._is_master:
+                    for k, v in full.items():
+                        if v.device.type == "cuda":
+                            buf = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
+                            buf.copy_(v, non_blocking=True)
+                            host[k] = buf
+                        else:
+                            host[k] = v
+                    if side is not None:
+                        copied = torch.cuda.Event()
+                        copied.record(side)
         # 4. write on a host thread
         if self._is_master:
             config = getattr(model, "config", None) if model is not None else None

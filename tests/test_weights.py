@@ -154,6 +154,46 @@ def test_side_stream_snapshot_is_not_disturbed_by_the_next_update(tmp_path, dtyp
     assert not torch.equal(state2["0.weight"], state["0.weight"])
 
 
+@pytest.mark.gpu
+def test_whole_tensors_go_out_through_one_staging_buffer_and_stay_tied(tmp_path):
+    """Tensors that share their memory (tied embeddings) share their slice of the staging buffer and come back
+    tied from the file; integer buffers keep their type; four publications in a row reuse the pinned buffers and
+    every file holds the weights of its own step."""
+    reset_world()
+    dev = torch.device("cuda:0")
+
+    class Tied(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.embed = nn.Embedding(1000, 64)
+            self.body = nn.Linear(64, 64)
+            self.head = nn.Linear(64, 1000, bias=False)
+            self.head.weight = self.embed.weight
+            self.register_buffer("steps", torch.arange(5))
+
+    torch.manual_seed(3)
+    model = Tied().to(dev).to(torch.bfloat16)
+    pub = WeightPublisher(tmp_path, async_level=8, device=dev)
+    want = []
+    for step in range(1, 5):
+        want.append({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+        pub.publish(model, step=step)
+        pub.guard_parameters()
+        with torch.no_grad():
+            for p in model.parameters():
+                p.mul_(1.5)
+    pub.wait_all()
+    assert len(pub._slots) <= pub.max_in_flight + 1
+    for step, w in zip(range(1, 5), want):
+        state = torch.load(tmp_path / "weights" / f"step_{step}" / "pytorch_model.bin", weights_only=True)
+        assert set(state) == set(w) and state["steps"].dtype == torch.int64
+        for k, v in w.items():
+            assert torch.equal(state[k], v), (step, k)
+        assert state["embed.weight"].data_ptr() == state["head.weight"].data_ptr()
+    size = (tmp_path / "weights" / "step_1" / "pytorch_model.bin").stat().st_size
+    assert size < 2 * (1000 * 64 + 64 * 64 + 64) + 16384  # the tied table is in the file once
+
+
 # --------------------------------------------------------------------------- device-to-device hand-off (gloo, CPU tensors)
 
 
