@@ -234,7 +234,7 @@ def _train(config: RLTrainerConfig, world: Any, device: torch.device, mesh: Any)
         else:
             res = T.train_step(model, optimizer, micro_batches, config.loss, config.optim.max_norm, device, scheduler,
                                samples=samples, recomputed_errors=errors)
-        publisher.maybe_clean(step)
+        publisher.maybe_clean(step, wait=False)
         seq_len = micro_batches[0]["input_ids"].shape[1]
         if counter is None:
             counter = perf.PerfCounter(model_cfg, seq_len, device_name=device_name, world_size=world.world_size)

@@ -101,12 +101,19 @@ class WeightPublisher:
     """Publishes HF-compatible bf16 weight files without stalling the step."""
 
     def __init__(self, output_dir: Path, interval: int | None = None, ckpt_interval: int | None = None,
-                 async_level: int = 2, device: torch.device | str | None = None, max_in_flight: int = 2):
+                 async_level: int = 2, device: torch.device | str | None = None, max_in_flight: int = 3):
         """`max_in_flight` publications may be on their way to the disk at once; a further `publish` first waits
         for the oldest (steps faster than the disk would otherwise pile up pinned host copies of the weights
         without bound, and pinning fresh host memory for every publication costs more than the copy itself:
-        ~100 ms per 3 GB)."""
+        ~100 ms per 3 GB).  Three writers keep up with a publication every ~90 ms for a 1.2 GB model (two: 135 ms;
+        more than three gain nothing, `tools/publish_profile.py`)."""
         self.max_in_flight = max(1, int(max_in_flight))
+        # torch.save of a 1.2 GB model takes 267 ms, 118 ms without the zip records' CRC32; torch.load reads
+        # either (other zip tools may complain about the second).  PRL_SAVE_CRC32=0 drops it, process-wide.
+        import os
+
+        if os.environ.get("PRL_SAVE_CRC32", "1") == "0" and hasattr(torch.serialization, "set_crc32_options"):
+            torch.serialization.set_crc32_options(False)
         self.weights_dir = get_weights_dir(output_dir)
         self.interval, self.ckpt_interval, self.async_level = interval, ckpt_interval, async_level
         self.device = torch.device(device) if device is not None else None
@@ -115,6 +122,7 @@ class WeightPublisher:
         self._subscribers: list[Callable[[dict[str, Tensor], int], None]] = []
         self._pending: list[PendingPublication] = []
         self._slots: list[Tensor] = []  # pinned staging buffers of the whole-tensor path
+        self._cleaners: list[threading.Thread] = []
 
     # ------------------------------------------------------------------ plumbing
 
@@ -286,6 +294,9 @@ class WeightPublisher:
     def wait_all(self) -> None:
         for p in list(self._pending):
             p.wait()
+        for t in self._cleaners:
+            t.join()
+        self._cleaners = []
 
     # ------------------------------------------------------------------ clean-up
 
@@ -299,17 +310,29 @@ class WeightPublisher:
         )
         return keep_for_eval or keep_for_ckpt
 
-    def maybe_clean(self, step: int) -> Path | None:
+    def maybe_clean(self, step: int, wait: bool = True) -> Path | None:
         """Consider deleting the directory of `async_level + 1` steps ago
-        (src/prime_rl/trainer/weights.py:211-228).  Returns the path removed, if any."""
+        (src/prime_rl/trainer/weights.py:211-228).  Returns the path removed, if any.  `wait=False` removes it on
+        a thread of its own, as the reference does (`weights.py:236-242`): unlinking a 1.2 GB file takes the
+        caller 23 ms; `wait_all` waits for those threads too."""
         old = max(step - (self.async_level + 1), 0)
         if self.keep_step(old):
             return None
         path = get_step_path(self.weights_dir, old)
-        for p in self._pending:  # a publication of that step still being written: let it finish, then remove it
-            if p.step == old and p._thread is not None and p._thread.is_alive():
-                p._thread.join()
-        shutil.rmtree(path, ignore_errors=True)
+        writers = [p._thread for p in self._pending if p.step == old and p._thread is not None]
+
+        def remove() -> None:
+            for t in writers:  # a publication of that step still being written: let it finish, then remove it
+                t.join()
+            shutil.rmtree(path, ignore_errors=True)
+
+        if wait:
+            remove()
+        else:
+            self._cleaners = [t for t in self._cleaners if t.is_alive()]
+            t = threading.Thread(target=remove, name=f"weight-cleanup-{old}")
+            t.start()
+            self._cleaners.append(t)
         return path
 
 

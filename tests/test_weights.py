@@ -55,7 +55,9 @@ def test_keep_and_clean_rule(tmp_path):
     assert pub.maybe_clean(8) == tmp_path / "weights" / "step_5" and not (tmp_path / "weights" / "step_5").exists()
     assert pub.maybe_clean(9) is None and (tmp_path / "weights" / "step_6").exists()  # kept for the checkpoint at 8
     no_rules = WeightPublisher(tmp_path, async_level=2)
-    assert no_rules.maybe_clean(6) == tmp_path / "weights" / "step_3"
+    assert no_rules.maybe_clean(6, wait=False) == tmp_path / "weights" / "step_3"  # on a thread of its own
+    no_rules.wait_all()
+    assert not (tmp_path / "weights" / "step_3").exists()
 
 
 def test_publications_in_flight_are_bounded(tmp_path):
