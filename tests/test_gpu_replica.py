@@ -291,7 +291,10 @@ def _replica_rank(rank, world, port, q, seed):
         rep = Replica(model, lambda m: torch.optim.SGD(m.parameters(), lr=1.0), compute_dtype=torch.float32)
         before = rep.state.flat16.clone()
         res = rep.train_step(mbs, prl.LossConfig(), max_norm=1e9)
-        q.put((rank, (before - rep.state.flat16).cpu(), res.grad_norm, res.stats["loss/mean"], res.stats["entropy/mean"]))
+        # a numpy array travels by value (a torch tensor would travel as a file descriptor this process must
+        # outlive)
+        q.put((rank, (before - rep.state.flat16).cpu().numpy(), res.grad_norm, res.stats["loss/mean"],
+               res.stats["entropy/mean"]))
     finally:
         dist.destroy_process_group()
 
@@ -309,10 +312,11 @@ def test_two_ranks_take_the_mean_of_their_own_steps():
     procs = [ctx.Process(target=_replica_rank, args=(r, 2, 29741, q, seed)) for r in range(2)]
     for p in procs:
         p.start()
-    results = sorted(q.get(timeout=180) for _ in procs)
+    results = [q.get(timeout=180) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    results = sorted(((r, torch.from_numpy(step), *rest) for r, step, *rest in results), key=lambda x: x[0])
     alone, losses = [], []
     for rank in range(2):
         gen = torch.Generator().manual_seed(seed + rank)
