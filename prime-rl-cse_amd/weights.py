@@ -108,11 +108,13 @@ class WeightPublisher:
         ~100 ms per 3 GB).  Three writers keep up with a publication every ~90 ms for a 1.2 GB model (two: 135 ms;
         more than three gain nothing, `tools/publish_profile.py`)."""
         self.max_in_flight = max(1, int(max_in_flight))
-        # torch.save of a 1.2 GB model takes 267 ms, 118 ms without the zip records' CRC32; torch.load reads
-        # either (other zip tools may complain about the second).  PRL_SAVE_CRC32=0 drops it, process-wide.
+        # torch.save of a 1.2 GB model takes 267 ms, 118 ms without the zip records' CRC32, which torch.load
+        # (what the inference worker and transformers read these files with) never looks at; other zip tools may
+        # complain about its absence.  The files are a hand-off that lives for async_level + 1 steps, so the
+        # checksum is left out (process-wide: torch has one switch) unless PRL_SAVE_CRC32=1 asks for it.
         import os
 
-        if os.environ.get("PRL_SAVE_CRC32", "1") == "0" and hasattr(torch.serialization, "set_crc32_options"):
+        if os.environ.get("PRL_SAVE_CRC32", "0") != "1" and hasattr(torch.serialization, "set_crc32_options"):
             torch.serialization.set_crc32_options(False)
         self.weights_dir = get_weights_dir(output_dir)
         self.interval, self.ckpt_interval, self.async_level = interval, ckpt_interval, async_level

@@ -187,7 +187,8 @@ def test_whole_tensors_go_out_through_one_staging_buffer_and_stay_tied(tmp_path)
     pub.wait_all()
     assert len(pub._slots) <= pub.max_in_flight + 1
     for step, w in zip(range(1, 5), want):
-        state = torch.load(tmp_path / "weights" / f"step_{step}" / "pytorch_model.bin", weights_only=True)
+        # read the way the reference's inference worker does (src/prime_rl/inference/vllm/worker.py:14-30)
+        state = torch.load(tmp_path / "weights" / f"step_{step}" / "pytorch_model.bin", weights_only=True, mmap=True)
         assert set(state) == set(w) and state["steps"].dtype == torch.int64
         for k, v in w.items():
             assert torch.equal(state[k], v), (step, k)
