@@ -195,6 +195,9 @@ def _train(config: RLTrainerConfig, world: Any, device: torch.device, mesh: Any)
         logprob_model, _ = build_model(config, device, mesh, dtype=torch.bfloat16, for_training=False,
                                        shard=replica is None)
         logprob_model.requires_grad_(False)
+    import os
+
+    publish = os.environ.get("PRL_PUBLISH", "1") != "0"  # 0: no weight files at all (to time the loop alone)
     snapshots: dict[int, dict[str, torch.Tensor]] = {}
     device_name = perf.describe_device(device)
     counter = None
@@ -203,7 +206,7 @@ def _train(config: RLTrainerConfig, world: Any, device: torch.device, mesh: Any)
     while config.max_steps is None or step < config.max_steps:
         t_step = time.perf_counter()
         t_save = 0.0
-        if step > 0:  # weights of step N go to the inference side while step N + 1 trains
+        if step > 0 and publish:  # weights of step N go to the inference side while step N + 1 trains
             t0 = time.perf_counter()
             publisher.publish(model, step)
             t_save = time.perf_counter() - t0
@@ -256,7 +259,7 @@ def _train(config: RLTrainerConfig, world: Any, device: torch.device, mesh: Any)
             f"Throughput: {row['perf/throughput']:.0f} tokens/s | MFU: {row['perf/mfu']:.1f}% | "
             f"Peak Mem.: {row['perf/peak_memory']:.1f} GiB")
         step += 1
-    if step > 0:  # the final weights, as the orchestrator waits for them
+    if step > 0 and publish:  # the final weights, as the orchestrator waits for them
         publisher.publish(model, step)
     publisher.wait_all()
     if config.bench and len(history) > 1:
