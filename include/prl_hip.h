@@ -286,6 +286,11 @@ int64_t prl_accumulate_chunk_elems(void);
 int prl_accumulate(const void* const* src, int src_dtype, const int64_t* dst_offset, const int64_t* numel,
                    const int32_t* chunk_tensor, const int64_t* chunk_start, int64_t n_chunks, const float* scale,
                    float* acc, void* stream);
+/* The first pass of a step: acc = scale * src for every tensor (zeros where src[i] is NULL) instead of
+ * acc += ...; the sums then need no clearing between steps and their old contents are not read. */
+int prl_accumulate_first(const void* const* src, int src_dtype, const int64_t* dst_offset, const int64_t* numel,
+                   const int32_t* chunk_tensor, const int64_t* chunk_start, int64_t n_chunks, const float* scale,
+                   float* acc, void* stream);
 
 /*
  * Causal self-attention over a packed row of SHORT samples (each at most 128 tokens, head dimension 128,

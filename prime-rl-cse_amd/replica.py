@@ -109,11 +109,12 @@ class FlatState:
         else:
             dist.all_gather_into_tensor(self.flat16, self._shard16, group=self.group)
 
-    def finish_step(self, optimizer: torch.optim.Optimizer, max_norm: float | None) -> Tensor:
+    def finish_step(self, optimizer: torch.optim.Optimizer, max_norm: float | None, keep_sums: bool = False) -> Tensor:
         """Mean of the ranks' gradient sums, clip by the global norm, optimizer step on the shard, new compute
         copy on every rank.  Returns the gradient norm before clipping (a 0-d tensor on the device; reading it
         is the caller's one host synchronisation).  Same clipping rule as torch.nn.utils.clip_grad_norm_,
-        which the reference calls (src/prime_rl/trainer/rl/train.py:336-338)."""
+        which the reference calls (src/prime_rl/trainer/rl/train.py:336-338).  `keep_sums` leaves the gradient
+        sums as they are (for a caller whose next step overwrites them); otherwise they are cleared."""
         if self.world > 1:
             grad = self._shard_grad
             if self._gloo():  # no reduce-scatter in gloo: reduce everything (on the host), keep the own part
@@ -140,9 +141,10 @@ class FlatState:
             if self.world > 1:
                 optimizer.step_flat(grad, coef, self._shard16)
                 self._gather_compute_copy()
-                self.acc32.zero_()
+                if not keep_sums:
+                    self.acc32.zero_()
             else:
-                optimizer.step_flat(grad, coef, self.flat16, zero_grad=True)
+                optimizer.step_flat(grad, coef, self.flat16, zero_grad=not keep_sums)
             return norm
         if coef is not None:
             grad.mul_(coef)
@@ -154,7 +156,8 @@ class FlatState:
             self._gather_compute_copy()
         else:
             self.flat16.copy_(self.master.detach())
-        self.acc32.zero_()
+        if not keep_sums:
+            self.acc32.zero_()
         return norm
 
 
@@ -197,6 +200,11 @@ class Replica:
         self._scale = torch.ones(1, dtype=torch.float32, device=self.device)
         self.replays = 0
         self.eager_runs = 0
+        # Without graphs the first pass of a step overwrites the gradient sums instead of adding to them, so nobody
+        # clears 4 bytes per parameter between steps or reads them back in that pass (0.9 ms of a 80 ms step).  A
+        # captured pass is the same launch whichever pass of a step replays it, so with graphs every pass adds
+        # and the optimizer step clears.
+        self._starts_sums = False
         # the chunk table of the accumulation kernel: parameter sizes never change
         lib = C.load()
         chunk = int(lib.prl_accumulate_chunk_elems())
@@ -251,11 +259,13 @@ class Replica:
             ptrs.append(g.data_ptr())
         return ptrs
 
-    def _accumulate(self, src: Tensor) -> None:
+    def _accumulate(self, src: Tensor, first: bool = False) -> None:
+        """`first`: the sums start with this pass (nothing cleared them, their old contents are not read)."""
         lib = C.load()
+        entry = lib.prl_accumulate_first if first else lib.prl_accumulate
         with C.on_device(self.device):
             C.check(
-                lib.prl_accumulate(C.ptr(src), C.dtype_code(self.state.flat16), C.ptr(self._offsets),
+                entry(C.ptr(src), C.dtype_code(self.state.flat16), C.ptr(self._offsets),
                                    C.ptr(self._numel), C.ptr(self._chunk_tensor), C.ptr(self._chunk_start),
                                    self._chunk_tensor.numel(), C.ptr(self._scale), C.ptr(self.state.acc32),
                                    C.stream_ptr(self.device)),
@@ -341,7 +351,8 @@ class Replica:
             return cap.loss.clone(), {k: cap.aux[k].clone() for k in _AUX_KEYS}
         loss, aux, grads, embed_grad = self._forward_backward(mb, plan, loss_config)
         src = host_to_device(self._grad_pointers(grads), self.device, torch.int64)
-        self._accumulate(src)
+        self._accumulate(src, first=self._starts_sums)
+        self._starts_sums = False
         self._embedding_backward(mb["input_ids"], embed_grad)
         del grads, embed_grad
         self._drop_grads()
@@ -365,6 +376,7 @@ class Replica:
         t0 = time.perf_counter()
         n_given = len(micro_batches)
         inv_scale = 1.0 / max(float(local_loss_scale(micro_batches, loss_config)), 1.0)
+        self._starts_sums = not self.graphs
         if skip_unscored and loss_config.ratio_type == "token":
             keep = scored(micro_batches)
             micro_batches = [micro_batches[i] for i in keep]
@@ -397,7 +409,7 @@ class Replica:
             tokens += int(mb["input_ids"].numel()) - (rows[step_idx].padding if rows is not None else 0)
         if n_given > len(micro_batches):  # every filler left out: a loss of 0, as the reference logs for it
             tensors.add("loss", torch.zeros(n_given - len(micro_batches), dtype=torch.float32, device=self.device))
-        grad_norm = self.state.finish_step(self.optimizer, max_norm)
+        grad_norm = self.state.finish_step(self.optimizer, max_norm, keep_sums=not self.graphs)
         if scheduler is not None:
             scheduler.step()
         stats = tensors.compute_stats()

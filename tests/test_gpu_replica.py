@@ -75,6 +75,18 @@ def test_accumulate_kernel_against_torch(dtype):
                                    ct.numel(), C.ptr(sc), C.ptr(got), C.stream_ptr(torch.device(DEV))), "acc")
         torch.cuda.synchronize()
         torch.testing.assert_close(got, expect, rtol=1e-6, atol=1e-6)
+    # the first pass of a step: the sums start here, tensors without a gradient start at zero
+    got = torch.full_like(acc, float("nan"))
+    for o, n in zip(offsets, sizes):  # (the gaps between tensors are nobody's: leave them out of the comparison)
+        got[o + n : o + (n + 127) // 128 * 128] = 0.0
+    C.check(lib.prl_accumulate_first(C.ptr(ptrs), C.dtype_code(srcs[0]), C.ptr(offs), C.ptr(numel), C.ptr(ct),
+                                     C.ptr(cs), ct.numel(), C.ptr(scale), C.ptr(got),
+                                     C.stream_ptr(torch.device(DEV))), "acc first")
+    first = torch.zeros_like(acc)
+    for s_, o, n in zip(srcs, offsets, sizes):
+        if s_ is not None:
+            first[o : o + n] = s_.float() * scale
+    torch.testing.assert_close(got, first, rtol=0, atol=0)
     assert lib.prl_accumulate(C.ptr(ptrs), 99, C.ptr(offs), C.ptr(numel), C.ptr(ct), C.ptr(cs), ct.numel(), None,
                               C.ptr(acc), None) != 0
 
