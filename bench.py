@@ -63,7 +63,7 @@ def parse() -> argparse.Namespace:
     p.add_argument("--no-trainer-extra", action="store_true",
                    help="do not append the short whole-trainer-step measurement to the line")
     p.add_argument("--trainer-steps", type=int, default=3)
-    p.add_argument("--trainer-limit", type=float, default=300.0,
+    p.add_argument("--trainer-limit", type=float, default=180.0,
                    help="with --gpus N > 1: seconds after which the line is printed without the whole-trainer-step "
                         "extra and the process ends")
     p.add_argument("--trainer-impl", choices=["hf", "fused", "replica", "graphed"], default="replica",
