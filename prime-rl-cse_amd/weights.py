@@ -209,8 +209,9 @@ class WeightPublisher:
                 flat = torch.empty(total, dtype=dtype, device=self.device)
                 staged = self._views(flat, layout)
                 first = {}  # one copy per slice: tied tensors share theirs
-                for name, _, off, _ in layout:
-                    first.setdefault(off, name)
+                for name, _, off, n in layout:
+                    if n:  # (an empty tensor takes no room: the next one starts at the same offset)
+                        first.setdefault(off, name)
                 torch._foreach_copy_([staged[k] for k in first.values()], [floating[k].detach() for k in first.values()])
                 full = {k: (staged[k] if k in staged else others[k]) for k in state}  # the state dict's own order
                 pending.snapshot_done = torch.cuda.Event()

@@ -172,6 +172,7 @@ def test_whole_tensors_go_out_through_one_staging_buffer_and_stay_tied(tmp_path)
             self.head = nn.Linear(64, 1000, bias=False)
             self.head.weight = self.embed.weight
             self.register_buffer("steps", torch.arange(5))
+            self.register_buffer("nothing", torch.zeros(0))  # an empty tensor ahead of the parameters' slices
 
     torch.manual_seed(3)
     model = Tied().to(dev).to(torch.bfloat16)
