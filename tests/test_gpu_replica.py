@@ -232,10 +232,11 @@ def test_joined_rows_give_the_step_of_the_separate_rows():
     joined, got = _three_steps(True, batches, loss_cfg, join_tokens=16384)
     assert joined.replays == 2 and joined.eager_runs == 1 and not joined.capture_errors  # one row of 640 tokens per step
     for i, ((n0, s0, f0, m0), (n1, s1, f1, m1)) in enumerate(zip(want, got)):
-        assert n1 == pytest.approx(n0, rel=5e-3)
+        # (bf16 products of other shapes round differently, and every AdamW step carries the difference on)
+        assert n1 == pytest.approx(n0, rel=5e-3 * (i + 1))
         assert s1.keys() == s0.keys()
         for k in s0:
-            assert s1[k] == pytest.approx(s0[k], rel=5e-3, abs=1e-6), k
+            assert s1[k] == pytest.approx(s0[k], rel=5e-3 * (i + 1), abs=1e-6), k
         # AdamW moves every weight by about lr per step; bf16 rounding in another summation order flips the sign
         # of the update only where the gradient is at the noise level
         assert (m1 - m0).norm().item() <= 0.3 * 1e-3 * m0.numel() ** 0.5 * (i + 1)
