@@ -271,7 +271,7 @@ def weight_grad(gy: Tensor, x: Tensor) -> Tensor:
     a, b = gy.view(s, rows // s, n_out).transpose(1, 2), x.view(s, rows // s, n_in)
     if size <= 3_200_000:
         return torch.bmm(a, b, out_dtype=torch.float32).sum(0).to(gy.dtype)
-    return torch.bmm(a, b).sum(0, dtype=torch.float32).to(gy.dtype)
+    return torch.bmm(a, b).sum(0)  # (a bf16 sum accumulates in fp32 and rounds once: one kernel, not a sum and a cast)
 
 
 class _Linear(torch.autograd.Function):
