@@ -351,6 +351,15 @@ int prl_qk_norm_rope_bwd(const void* gq, const int64_t* gq_strides, const void* 
                          int64_t k_heads, void* stream);
 
 /*
+ * Number of nodes of a captured HIP graph (`graph` is a hipGraph_t, child graphs included) and how many of them
+ * are memset nodes.  No counterpart in the reference, which never captures graphs
+ * (src/prime_rl/trainer/model.py:219-230 hands the blocks to a tracing compiler instead): the whole-model
+ * trainer calls this between capture and instantiation and refuses to replay a pass that holds memset nodes,
+ * which library calls record under capture.  Host-only: launches nothing.
+ */
+int prl_graph_node_counts(void* graph, int64_t* n_nodes, int64_t* n_memset_nodes);
+
+/*
  * Group-relative advantages: B rewards in consecutive groups of G.  Replaces
  * compute_advantages (src/prime_rl/orchestrator/advantage.py:71-103) for the
  * four kinds of its REGISTRY (:63-68).  `lengths` (int64 [B], completion

@@ -1,5 +1,4 @@
-"""Data-parallel training of a model that fits whole on every MI355X, with each
-micro-batch replayed from a HIP graph.
+"""Data-parallel training of a model that fits whole on every MI355X.
 
 The reference shards every model with FSDP2 and, when `model.compile` is set,
 hands the blocks to a tracing compiler (src/prime_rl/trainer/model.py:102-135,
@@ -15,8 +14,11 @@ quarter of the time.  So here:
     shards plus `MixedPrecisionPolicy(param_dtype=bf16, reduce_dtype=fp32)` are
     in the reference);
   * a micro-batch (forward, the HIP loss path, backward, gradient accumulation)
-    is captured once per input shape in a HIP graph and replayed: one launch
-    from the host instead of thousands.  Shapes seen for the first time, and
+    runs eagerly by default.  With `graphs=True` it is captured once per input
+    shape in a HIP graph and replayed (one launch from the host instead of
+    thousands), but only if the captured graph holds no memset node: library
+    calls record them under capture, replays of such nodes have gone wrong on
+    MI355X boxes, and a graph that holds one is refused (`GraphHoldsMemsets`).  Shapes seen for the first time, and
     more distinct shapes than `max_graphs`, run eagerly through the same code
     (a graph keeps its activations' memory: ~30 GB for a 16 K-token row of the
     0.6B model, so `max_graphs` = 4 is sized for 288 GB);
@@ -161,6 +163,21 @@ class FlatState:
         return norm
 
 
+class GraphHoldsMemsets(RuntimeError):
+    """A captured pass holds memset nodes.  Replays of such graphs have gone wrong on MI355X boxes (a node left
+    the memory it should clear as it was), so the graph is thrown away before it is ever launched."""
+
+
+def graph_node_counts(graph: Any) -> tuple[int, int]:
+    """(nodes, memset nodes) of a captured `torch.cuda.CUDAGraph(keep_graph=True)`; host-side queries only."""
+    import ctypes
+
+    nodes, memsets = ctypes.c_int64(0), ctypes.c_int64(0)
+    C.check(C.load().prl_graph_node_counts(ctypes.c_void_p(int(graph.raw_cuda_graph())), ctypes.byref(nodes),
+                                           ctypes.byref(memsets)), "prl_graph_node_counts")
+    return int(nodes.value), int(memsets.value)
+
+
 class _Captured:
     """One captured micro-batch shape: the graph, the buffers it reads and the tensors it leaves behind."""
 
@@ -197,6 +214,7 @@ class Replica:
         self._captured: "OrderedDict[tuple, _Captured]" = OrderedDict()
         self._seen: set[tuple] = set()
         self.capture_errors: dict[tuple, str] = {}
+        self.graph_nodes: dict[tuple, tuple[int, int]] = {}  # per captured shape: (nodes, memset nodes)
         self._scale = torch.ones(1, dtype=torch.float32, device=self.device)
         self.replays = 0
         self.eager_runs = 0
@@ -307,13 +325,22 @@ class Replica:
                 if getattr(plan, name) is not None:
                     setattr(cap.plan, name, getattr(plan, name).clone())
         cap.src = torch.zeros(len(self.state.params), dtype=torch.int64, device=self.device)
-        cap.graph = torch.cuda.CUDAGraph()
+        cap.graph = torch.cuda.CUDAGraph(keep_graph=True)  # kept, so that its nodes can be looked at before it runs
         with torch.cuda.graph(cap.graph):
             cap.loss, cap.aux, grads, cap.embed_grad = self._forward_backward(cap.inputs, cap.plan, loss_config)
             ptrs = self._grad_pointers(grads)
             self._accumulate(cap.src)
             del grads
             self._drop_grads()
+        nodes, memsets = graph_node_counts(cap.graph)
+        self.graph_nodes[self._key(mb, plan, loss_config)] = (nodes, memsets)
+        if memsets:
+            cap.graph.reset()
+            raise GraphHoldsMemsets(
+                f"Replica: the captured pass holds {memsets} memset nodes among its {nodes} (library calls record "
+                "them under capture, e.g. hipBLASLt's stream-K products clearing their flags); such a graph is "
+                "never replayed here. Run without graphs (PRL_GRAPHS=0, the default).")
+        cap.graph.instantiate()
         # nothing has run yet: the graph reads this table when it is replayed
         cap.src.copy_(torch.tensor(ptrs, dtype=torch.int64))
         return cap
@@ -326,6 +353,9 @@ class Replica:
         if cap is None and self.graphs and key in self._seen and key not in self.capture_errors:
             try:
                 cap = self._capture(mb, plan, loss_config)
+            except GraphHoldsMemsets:
+                self._drop_grads()
+                raise
             except RuntimeError as e:  # something in this shape's forward cannot be captured: it stays eager
                 self.capture_errors[key] = repr(e)
                 self._drop_grads()

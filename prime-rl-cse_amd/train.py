@@ -52,17 +52,20 @@ def trainer_mode(config: RLTrainerConfig) -> str:
 
 
 def replay_graphs(config: RLTrainerConfig) -> bool:
-    """Whether the whole-model trainer replays its micro-batches from HIP graphs: only when asked, by
-    `[model.compile]` in the recipe (the reference's opt-in for its tracing compiler) or PRL_GRAPHS=1;
-    PRL_GRAPHS=0 overrides the recipe.  Off otherwise: with a step's rows joined into one pass replay saves about
-    1 %, and a captured graph holds the memset nodes that library calls record (hipBLASLt's stream-K products
-    clear their flags that way), which this build's own kernels avoid inside graphs."""
+    """Whether the whole-model trainer replays its micro-batches from HIP graphs: only under PRL_GRAPHS=1, and
+    then `Replica` looks at every captured pass before it runs and raises if it holds a memset node (library
+    calls record them under capture: hipBLASLt's stream-K products clear their flags that way, about 130 per
+    pass of the 0.6B model, and replays of such nodes have gone wrong on MI355X boxes).  `[model.compile]` in a
+    recipe, the reference's opt-in for its tracing compiler, selects the whole-model trainer
+    (`trainer_mode`) but no longer graph replay: with a step's rows joined into one pass replay saved 1 %."""
     import os
 
-    env = os.environ.get("PRL_GRAPHS", "")
-    if env in ("0", "1"):
-        return env == "1"
-    return config.model.compile is not None
+    if os.environ.get("PRL_GRAPHS", "") == "1":
+        return True
+    if config.model.compile is not None:
+        log("[model.compile]: whole model per GPU, passes run eagerly (graph replay is off: captured library "
+            "calls hold memset nodes; PRL_GRAPHS=1 captures, checks for them and refuses a graph that has any)")
+    return False
 
 
 def fused_blocks(config: RLTrainerConfig) -> bool:

@@ -1,4 +1,4 @@
-"""`Replica` (whole model per GPU, micro-batches replayed from HIP graphs): the accumulation kernel against
+"""`Replica` (whole model per GPU; graph replay of its passes is switched off, see REPLAY_OFF): the accumulation kernel against
 torch, a step against the same model on the CPU with the oracle's loss, and replayed graphs against the same
 code run eagerly, replay by replay, on data that changes every time."""
 
@@ -16,6 +16,11 @@ from prime_rl_cse_amd.replica import Replica, eligible
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+
+REPLAY_OFF = ("graph replay is switched off: a captured pass holds the memset nodes that library calls record "
+              "(hipBLASLt's stream-K flags), replays of such nodes have given a memory fault on an MI355X box, and "
+              "Replica now refuses a graph that holds any before it is launched")
+
 
 
 def tiny_config(vocab=2048):
@@ -91,8 +96,9 @@ def test_accumulate_kernel_against_torch(dtype):
                               C.ptr(acc), None) != 0
 
 
+@pytest.mark.parametrize("graphs", [False, pytest.param(True, marks=pytest.mark.skip(reason=REPLAY_OFF))])
 @pytest.mark.parametrize("ratio_type,join", [("token", 0), ("sequence", 0), ("token", 16384)])
-def test_fp32_replica_step_matches_cpu_model_with_oracle_loss(ratio_type, join):
+def test_fp32_replica_step_matches_cpu_model_with_oracle_loss(ratio_type, join, graphs):
     cfg = tiny_config()
     cpu_model = T.get_model(cfg, "cpu", torch.float32, seed=3)
     gpu_model = copy.deepcopy(cpu_model).to(DEV)
@@ -113,12 +119,12 @@ def test_fp32_replica_step_matches_cpu_model_with_oracle_loss(ratio_type, join):
         cpu_losses.append(loss.item())
     cpu_norm = torch.nn.utils.clip_grad_norm_(cpu_model.parameters(), 1e9).item()
 
-    rep = Replica(gpu_model, lambda m: torch.optim.SGD(m.parameters(), lr=1.0), graphs=True,
+    rep = Replica(gpu_model, lambda m: torch.optim.SGD(m.parameters(), lr=1.0), graphs=graphs,
                   compute_dtype=torch.float32)
     before = rep.state.master.detach().clone()
     res = rep.train_step(mbs, loss_cfg, max_norm=1e9, join_tokens=join)
-    # apart: eager, capture + replay, replay, replay; joined: the four rows are one row of 256 tokens
-    assert (rep.eager_runs, rep.replays) == ((1, 3) if join == 0 else (1, 0))
+    # apart with graphs: eager, capture + replay, replay, replay; joined: the four rows are one row of 256 tokens
+    assert (rep.eager_runs, rep.replays) == (((1, 3) if graphs else (4, 0)) if join == 0 else (1, 0))
     assert abs(res.grad_norm - cpu_norm) <= 2e-4 * cpu_norm
     assert abs(res.stats["loss/mean"] - sum(cpu_losses) / len(cpu_losses)) <= 1e-4
     step = before - rep.state.master.detach()  # SGD with lr 1: the step is the gradient
@@ -144,6 +150,37 @@ def _three_steps(graphs, batches, loss_cfg, max_graphs=4, join_tokens=0):
     return rep, out
 
 
+def test_captured_graphs_are_checked_for_memset_nodes_before_they_run():
+    """`graph_node_counts` on two captures that are never launched: one of kernels only (torch's `zero_()` is a
+    fill kernel) and one that also records a hipMemsetAsync on the capturing stream."""
+    import ctypes
+    from pathlib import Path
+
+    from prime_rl_cse_amd.replica import graph_node_counts
+
+    hip = ctypes.CDLL(str(Path(torch.__file__).parent / "lib" / "libamdhip64.so"))  # the runtime torch has loaded
+    hip.hipMemsetAsync.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
+    x = torch.ones(1024, device=DEV)
+    torch.cuda.synchronize()
+    clean = torch.cuda.CUDAGraph(keep_graph=True)
+    with torch.cuda.graph(clean):
+        x.mul_(2.0)
+        x.zero_()
+    nodes, memsets = graph_node_counts(clean)
+    assert nodes >= 2 and memsets == 0
+    dirty = torch.cuda.CUDAGraph(keep_graph=True)
+    with torch.cuda.graph(dirty):
+        x.mul_(2.0)
+        rc = hip.hipMemsetAsync(x.data_ptr(), 0, 64, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    nodes, memsets = graph_node_counts(dirty)
+    assert nodes >= 2 and memsets == 1
+    clean.reset()
+    dirty.reset()
+    assert torch.equal(x.cpu(), torch.ones(1024))  # nothing ran
+
+
+@pytest.mark.skip(reason=REPLAY_OFF)
 @pytest.mark.parametrize("ratio_type", ["token", "sequence"])
 def test_replayed_graphs_match_eager_runs_on_changing_data(ratio_type):
     gen = torch.Generator().manual_seed(9)
@@ -162,6 +199,7 @@ def test_replayed_graphs_match_eager_runs_on_changing_data(ratio_type):
         assert (f1 != f0).float().mean().item() < 1e-3  # bf16 copies: the odd rounding flip at most
 
 
+@pytest.mark.skip(reason=REPLAY_OFF)
 def test_ragged_rows_of_several_shapes_and_graph_eviction():
     gen = torch.Generator().manual_seed(13)
     loss_cfg = prl.LossConfig()
@@ -228,9 +266,9 @@ def test_joined_rows_give_the_step_of_the_separate_rows():
             mb["loss_mask"] = torch.ones_like(mb["loss_mask"])
             mb["logprobs"] = -8.3 + 0.2 * torch.randn(mb["logprobs"].shape, generator=gen)  # near -ln V: row starts unclipped
         batches.append(mbs)
-    apart, want = _three_steps(True, batches, loss_cfg, join_tokens=0)
-    joined, got = _three_steps(True, batches, loss_cfg, join_tokens=16384)
-    assert joined.replays == 2 and joined.eager_runs == 1 and not joined.capture_errors  # one row of 640 tokens per step
+    apart, want = _three_steps(False, batches, loss_cfg, join_tokens=0)
+    joined, got = _three_steps(False, batches, loss_cfg, join_tokens=16384)
+    assert joined.replays == 0 and joined.eager_runs == 3  # one row of 640 tokens per step
     for i, ((n0, s0, f0, m0), (n1, s1, f1, m1)) in enumerate(zip(want, got)):
         # (bf16 products of other shapes round differently, and every AdamW step carries the difference on)
         assert n1 == pytest.approx(n0, rel=5e-3 * (i + 1))

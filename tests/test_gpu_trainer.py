@@ -197,9 +197,11 @@ def test_trainer_entry_point_on_fake_data(tmp_path, monkeypatch):
     assert state["model.embed_tokens.weight"].shape == (151936, 1024)
 
 
-def test_trainer_entry_point_with_model_compile_replays_graphs(tmp_path, monkeypatch):
-    """`[model.compile]` selects the whole-model-per-GPU mode with micro-batches replayed from HIP graphs; the
-    run logs what the FSDP2 run of the same configuration logs."""
+def test_trainer_entry_point_with_model_compile_takes_whole_model_mode(tmp_path, monkeypatch):
+    """`[model.compile]` selects the whole-model-per-GPU mode (its passes run eagerly: graph replay is off, a
+    captured pass holds the memset nodes of library calls); the run logs what the FSDP2 run of the same
+    configuration logs."""
+    monkeypatch.delenv("PRL_GRAPHS", raising=False)
     from prime_rl_cse_amd.settings import RLTrainerConfig, parse_argv
     from prime_rl_cse_amd.train import train
 
@@ -256,8 +258,9 @@ def test_trainer_entry_point_on_rollout_files(tmp_path, monkeypatch):
 
 def test_rollout_files_through_both_trainers_agree(tmp_path, monkeypatch):
     """Ragged rollouts (prompts masked, completions of many lengths, several rows per step) from
-    `rollouts/step_N/rank_0.pt` through the FSDP2 trainer and through the whole-model trainer with graphs, fused
+    `rollouts/step_N/rank_0.pt` through the FSDP2 trainer and through the whole-model trainer, fused
     blocks on in both: the same logged numbers step by step."""
+    monkeypatch.delenv("PRL_GRAPHS", raising=False)
     from prime_rl_cse_amd.settings import RLTrainerConfig
     from prime_rl_cse_amd.train import train
 

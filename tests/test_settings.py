@@ -123,7 +123,8 @@ def test_trainer_mode_and_block_kernels_follow_the_recipe(monkeypatch):
     from prime_rl_cse_amd.train import replay_graphs
 
     monkeypatch.delenv("PRL_GRAPHS", raising=False)
-    assert replay_graphs(RLTrainerConfig(model={"compile": {}})) and not replay_graphs(RLTrainerConfig())
+    # the recipe's switch picks the whole-model trainer but never graph replay
+    assert not replay_graphs(RLTrainerConfig(model={"compile": {}})) and not replay_graphs(RLTrainerConfig())
     monkeypatch.setenv("PRL_GRAPHS", "0")
     assert not replay_graphs(RLTrainerConfig(model={"compile": {}}))
     monkeypatch.setenv("PRL_GRAPHS", "1")
