@@ -42,9 +42,10 @@ SEQ_LEN = 128
 MICRO_BATCH = 16
 BATCH = 128
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+EXIT_TRAINER_EXTRA_HUNG = 3  # exit code when the whole-trainer-step extra (or the barrier behind it) never returned
 
 
-def parse() -> argparse.Namespace:
+def parse(argv: list[str] | None = None) -> argparse.Namespace:
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=10)
@@ -66,12 +67,15 @@ def parse() -> argparse.Namespace:
     p.add_argument("--trainer-limit", type=float, default=180.0,
                    help="with --gpus N > 1: seconds after which the line is printed without the whole-trainer-step "
                         "extra and the process ends")
+    p.add_argument("--launch-check", action="store_true",
+                   help="ranks only meet, all-reduce one number and rank 0 prints what it saw: a test of the launch "
+                        "path that needs no GPU (with PRL_BENCH_BACKEND=gloo)")
     p.add_argument("--trainer-impl", choices=["hf", "fused", "replica", "graphed"], default="replica",
                    help="whole-trainer-step workload: hf = the transformers blocks as they are under FSDP2; fused = "
                         "their RMSNorm / rotary / SwiGLU on this package's HIP kernels (the reference's model.impl = "
                         "liger_kernel); replica = fused, the whole model on every GPU with sharded master weights; "
                         "graphed = replica with every micro-batch replayed from a HIP graph")
-    return p.parse_args()
+    return p.parse_args(argv)
 
 
 def make_batch(dev, dtype, kind: str, seed: int):
@@ -303,18 +307,111 @@ def trainer_cpu_baseline(batch, seconds: float) -> dict:
                       f"(forward, oracle loss, backward) plus one clip + AdamW step, {el:.1f} s"}
 
 
-def main() -> None:
-    args = parse()
+def free_port() -> int:
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return int(s.getsockname()[1])
+
+
+def rank_commands(n: int, argv: list[str], port: int, environ: dict[str, str] | None = None
+                  ) -> list[tuple[list[str], dict[str, str]]]:
+    """(argv, environment) of the N rank processes of `python bench.py --gpus N ...` on this node: this same
+    script under a fresh interpreter, one per GPU, with the rendezvous variables torch.distributed.run would
+    set (the reference starts its trainer ranks through torchrun from its launcher,
+    src/prime_rl/rl.py:589-623)."""
+    base = dict(os.environ if environ is None else environ)
+    out = []
+    for r in range(n):
+        env = {**base, "RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+               "GROUP_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "PYTHONUNBUFFERED": "1",
+               "PRL_BENCH_LAUNCHED": "1"}
+        out.append(([sys.executable, "-u", str(Path(__file__).resolve()), *argv], env))
+    return out
+
+
+def launch_ranks(n: int, argv: list[str], grace: float = 30.0) -> int:
+    """Starts the N ranks as children, passes rank 0's JSON line through to stdout (everything else the ranks
+    print goes to stderr) and returns the worst exit code.  When a rank fails the others get `grace` seconds
+    to end by themselves and are then killed, as the reference's launcher ends every process once one has
+    failed (src/prime_rl/rl.py:641-651).  This process makes no GPU call: the ranks are fresh processes."""
+    import subprocess
+
+    procs = []
+    for r, (cmd, env) in enumerate(rank_commands(n, argv, free_port())):
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr,
+                                      stderr=sys.stderr, text=True))
+
+    def relay() -> None:
+        for text in procs[0].stdout:
+            is_line = False
+            if text.startswith("{"):
+                try:
+                    is_line = "metric" in json.loads(text)
+                except ValueError:
+                    pass
+            (sys.stdout if is_line else sys.stderr).write(text)
+            (sys.stdout if is_line else sys.stderr).flush()
+
+    reader = threading.Thread(target=relay, daemon=True)
+    reader.start()
+    failed_at = None
+    while any(p.poll() is None for p in procs):
+        if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
+            failed_at = time.monotonic()
+        if failed_at is not None and time.monotonic() - failed_at > grace:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.2)
+    reader.join(timeout=10)
+    codes = [p.returncode for p in procs]
+    worst = max((128 - c if c < 0 else c) for c in codes)  # a rank ended by signal S counts as 128 + S
+    if worst:
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr, flush=True)
+    return worst
+
+
+def launch_check(rank: int, world: int, backend: str, local: int) -> None:
+    """The ranks meet, add up their ranks and rank 0 prints a line.  With RCCL the number travels through the
+    GPUs; with gloo nothing touches one."""
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        x = torch.tensor([float(rank)], device=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend)
+        x = torch.tensor([float(rank)])
+    dist.all_reduce(x)
+    names = [None] * world
+    dist.all_gather_object(names, f"rank {rank}: " + (torch.cuda.get_device_name(local) if backend == "nccl" else "cpu"))
+    if rank == 0:
+        print(json.dumps({"metric": "launch_check", "value": float(x.item()), "unit": "sum of ranks",
+                          "n_gpus": world, "backend": dist.get_backend(), "ranks": dist.get_world_size(),
+                          "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0, "devices": names,
+                          "gpu_initialised": torch.cuda.is_initialized()}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def main(argv: list[str] | None = None) -> int:
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: this process only starts the ranks and waits for them
+        return launch_ranks(args.gpus, argv)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with torch.distributed.run, one rank per GPU")
     # one rank per GPU over RCCL.  PRL_BENCH_BACKEND=gloo is a rehearsal aid for boxes with fewer GPUs than
     # ranks: ranks then share devices round-robin and exchange through host memory.
     backend = os.environ.get("PRL_BENCH_BACKEND", "nccl")
+    if args.launch_check:
+        launch_check(rank, world, backend, local)
+        return 0
     local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -343,7 +440,7 @@ def main() -> None:
         if dist.is_initialized():
             dist.barrier()
             dist.destroy_process_group()
-        return
+        return 0
 
     dtype = torch.bfloat16 if args.logits_dtype == "bf16" else torch.float32
     es = 2 if dtype == torch.bfloat16 else 4
@@ -392,6 +489,12 @@ def main() -> None:
     elapsed = float(el.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = world * BATCH / (elapsed / args.steps)
+    # who took part: one entry per rank, and the size of the RCCL communicator the timing all-reduce went through
+    devices = [f"rank {rank}: cuda:{local} {torch.cuda.get_device_name(dev)}"]
+    if world > 1:
+        devices = [None] * world
+        dist.all_gather_object(devices, f"rank {rank}: cuda:{local} {torch.cuda.get_device_name(dev)}")
+    rccl_ranks = dist.get_world_size() if dist.is_initialized() and dist.get_backend() == "nccl" else 0
 
     line = None
     if rank == 0:
@@ -423,8 +526,12 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32",  # the arithmetic; the logits and their gradient are stored as `storage_dtype`
+            "storage_dtype": args.logits_dtype,
             "data": "synthetic",
+            "rccl_ranks": rccl_ranks,
+            "backend": dist.get_backend() if dist.is_initialized() else "none (one rank)",
+            "devices": devices,
             "config": {
                 "workload": "Qwen3-0.6B reverse_text GRPO policy update from resident logits: per step 8 packed rows "
                             f"of T={t} tokens x V={VOCAB} {args.logits_dtype} logits -> sample boundaries, logprob, "
@@ -482,10 +589,11 @@ def main() -> None:
                 print(json.dumps(line), flush=True)
 
     def bail() -> None:
+        # a collective that never came back: the headline still goes out, the exit code says that the run hung
         if rank == 0:
             line.setdefault("trainer_step", {"error": f"no result within {args.trainer_limit:.0f} s"})
         emit()
-        os._exit(0)
+        os._exit(EXIT_TRAINER_EXTRA_HUNG)
 
     watchdog = None
     if world > 1 and not args.no_trainer_extra:
@@ -506,7 +614,8 @@ def main() -> None:
         if watchdog is not None:
             watchdog.cancel()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -82,13 +82,11 @@ __global__ void k_stats_begin(void* base, int K) {
   const Layout l = layout_for(K);
   int* w = (int*)base;
   const int64_t words = l.total / 4;
+  // every word is written exactly once, by the thread that owns it, with the value it starts from: the extrema
+  // (kept as "largest so far" of an order key and of its complement) start at the lowest key, the rest at zero
+  const int64_t ext_lo = l.ext / 4, ext_hi = ext_lo + 2 * (int64_t)K;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (int64_t)gridDim.x * blockDim.x)
-    w[i] = 0;
-  __syncthreads();
-  if (blockIdx.x == 0) {
-    int* ext = (int*)((char*)base + l.ext);
-    for (int i = threadIdx.x; i < 2 * K; i += blockDim.x) ext[i] = (int)0x80000000;
-  }
+    w[i] = (i >= ext_lo && i < ext_hi) ? (int)0x80000000 : 0;
 }
 
 // Walk the digit histograms of levels 0 .. level-1 of `key` to find the prefix

@@ -208,6 +208,7 @@ def _train(config: RLTrainerConfig, world: Any, device: torch.device, mesh: Any)
     step = 0
     while config.max_steps is None or step < config.max_steps:
         t_step = time.perf_counter()
+        torch.cuda.reset_peak_memory_stats(device)  # the step's own peak, as src/prime_rl/trainer/rl/train.py:159
         t_save = 0.0
         if step > 0 and publish:  # weights of step N go to the inference side while step N + 1 trains
             t0 = time.perf_counter()

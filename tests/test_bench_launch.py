@@ -1,0 +1,77 @@
+"""`python bench.py --gpus N` by itself: the parent starts N fresh rank processes, passes rank 0's one JSON line
+through and returns the worst exit code, and never makes a GPU call of its own (what the reference's launcher
+does for its trainer ranks, src/prime_rl/rl.py:589-651).  All on the CPU: the ranks meet over gloo."""
+
+import json
+import os
+import subprocess
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO))
+import bench  # noqa: E402
+
+
+def test_rank_commands_carry_the_rendezvous_of_one_node():
+    cmds = bench.rank_commands(4, ["--gpus", "4", "--steps", "7"], 29999, environ={"HOME": "/x", "WORLD_SIZE": "9"})
+    assert len(cmds) == 4
+    for r, (argv, env) in enumerate(cmds):
+        assert argv[0] == sys.executable and Path(argv[2]) == REPO / "bench.py"
+        assert argv[3:] == ["--gpus", "4", "--steps", "7"]
+        assert env["RANK"] == env["LOCAL_RANK"] == str(r)
+        assert env["WORLD_SIZE"] == env["LOCAL_WORLD_SIZE"] == "4"
+        assert env["MASTER_ADDR"] == "127.0.0.1" and env["MASTER_PORT"] == "29999"
+        assert env["HOME"] == "/x"
+
+
+def test_two_ranks_meet_over_gloo_and_one_line_comes_out():
+    env = {**os.environ, "PRL_BENCH_BACKEND": "gloo"}
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                         capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [x for x in out.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1  # rank 0's line and nothing else on stdout
+    line = json.loads(lines[0])
+    assert line["ranks"] == 2 and line["n_gpus"] == 2 and line["value"] == 1.0  # ranks 0 + 1
+    assert line["devices"] == ["rank 0: cpu", "rank 1: cpu"]
+    assert line["gpu_initialised"] is False
+
+
+def _fake_ranks(monkeypatch, scripts):
+    def commands(n, argv, port, environ=None):
+        assert n == len(scripts)
+        return [([sys.executable, "-c", code], dict(os.environ)) for code in scripts]
+
+    monkeypatch.setattr(bench, "rank_commands", commands)
+
+
+def test_parent_relays_only_the_json_line_and_never_touches_the_gpu(monkeypatch, capfd):
+    _fake_ranks(monkeypatch, [
+        'print("noise from rank 0"); print(\'{"metric": "m", "value": 1}\'); print(\'{"other": 1}\')',
+        'print("noise from rank 1")',
+    ])
+    assert bench.launch_ranks(2, []) == 0
+    out, err = capfd.readouterr()
+    assert out.strip() == '{"metric": "m", "value": 1}'
+    assert "noise from rank 0" in err and "noise from rank 1" in err and '{"other": 1}' in err
+    assert not torch.cuda.is_initialized()
+
+
+def test_a_failing_rank_ends_the_others_and_sets_the_exit_code(monkeypatch, capfd):
+    _fake_ranks(monkeypatch, ["import time; time.sleep(600)", "import sys; sys.exit(7)"])
+    t0 = time.monotonic()
+    assert bench.launch_ranks(2, [], grace=1.0) == 137  # rank 0 was killed (128 + SIGKILL), rank 1 left with 7
+    assert time.monotonic() - t0 < 60
+    assert "rank exit codes" in capfd.readouterr().err
+
+
+def test_the_hung_extra_has_a_nonzero_exit_code():
+    assert bench.EXIT_TRAINER_EXTRA_HUNG != 0
+    src = (REPO / "bench.py").read_text()
+    assert "os._exit(EXIT_TRAINER_EXTRA_HUNG)" in src and "os._exit(0)" not in src

@@ -444,6 +444,26 @@ def test_tensors_many_keys_many_pieces():
         assert abs(got[f"{key}/std"] - w["std"]) <= 1e-4 * w["std"]
 
 
+def test_tensors_with_forty_keys_of_one_sign_each():
+    """More keys than fit the first 256 words of the scratch, every key all-positive or all-negative: minimum
+    and maximum come out right only if every extremum started from "nothing seen yet" (each scratch word gets
+    its starting value from the thread that owns it)."""
+    gen = torch.Generator().manual_seed(7)
+    for _ in range(3):  # fresh scratch contents from the allocator's reuse each time
+        tensors = prl.Tensors()
+        want = {}
+        for k in range(40):
+            x = torch.rand(257 + 31 * k, generator=gen) + 0.25
+            if k % 2:
+                x = -x
+            tensors.add(f"key{k}", x.to(DEV))
+            want[f"key{k}"] = O.tensor_stats(x)
+        got = tensors.compute_stats()
+        for key, w in want.items():
+            for name in ("median", "min", "max"):
+                assert got[f"{key}/{name}"] == w[name], (key, name)
+
+
 def _stats_rank(rank, world, port, q):
     import os
 
