@@ -273,6 +273,58 @@ def golden_epilogue(R, grl, LossConfig) -> int:
     return n
 
 
+def golden_full_vocabulary(R, grl, LossConfig) -> int:
+    """Whole-epilogue vectors at the vocabularies of the recipes' models (151936: Qwen3 / Qwen2.5 small;
+    152064: the 7B and 32B distillations) and the sampling temperature of the long-context recipe (0.6), bf16
+    logits as the model emits them.  Few rows, so that a case stays a few MB.  Next to the reference's fp32
+    entropy the file holds a float64 evaluation of the same formula: at this size the reference's own fp32 sums
+    are a few 1e-4 away from it, which is what a test needs to know to judge a third implementation."""
+    n = 0
+    for i, (name, vocab, lengths) in enumerate([("v151936", 151936, [3, 5]), ("v152064", 152064, [6, 2])]):
+        gen = torch.Generator().manual_seed(7000 + i)
+        temp = 0.6
+        t = sum(lengths)
+        pos = torch.cat([torch.arange(k) for k in lengths])
+        ids = torch.randint(0, vocab, (t,), generator=gen)
+        ids[-1] = vocab - 1  # the last column of the matrix is somebody's label
+        mask = torch.ones(t, dtype=torch.bool)
+        mask[0] = mask[4] = False
+        logits = (torch.randn(1, t, vocab, generator=gen) * 2.5).to(torch.bfloat16)
+        adv = torch.randn(t, generator=gen)
+        with torch.no_grad():
+            x = O.shift_logits(logits.float()) / temp
+            lp0 = O.selective_log_softmax(x, ids.unsqueeze(0)).squeeze(0)
+            x64 = x.double()
+            ent64 = (torch.logsumexp(x64, -1) - (torch.softmax(x64, -1) * x64).sum(-1))[0]
+            lp64 = (x64.gather(-1, ids.view(1, t, 1)).squeeze(-1) - torch.logsumexp(x64, -1))[0]
+        old = lp0 + 0.2 * torch.randn(t, generator=gen)
+        cfg = LossConfig(ratio_type="token", ratio_length_norm=False, clip_ratio=8.0)
+        scale = int(mask.sum().item())
+        b = lambda v: v.unsqueeze(0)
+        ref = reference_epilogue(R, logits, b(ids), b(pos), b(adv), b(old), b(mask), temp, cfg, scale, grl)
+        ocl = O.policy_epilogue(logits, b(ids), b(pos), b(adv), b(old), b(mask), temp,
+                                O.LossConfig("token", False, 8.0), scale)
+        for k in ref:
+            must(ref[k] == ocl[k] if k == "lengths" else same(ref[k], ocl[k]), f"full_{name}.{k}")
+        print(f"  full_{name}: reference fp32 vs float64: entropy {(ref['entropy'][0].double() - ent64).abs().max():.2e}, "
+              f"logprob {(ref['logprobs'][0].double() - lp64).abs().max():.2e}")
+        np.savez_compressed(
+            OUT / f"full_{name}.npz",
+            **npify({
+                "logits": logits[0], "input_ids": ids, "position_ids": pos, "advantages": adv, "old_logprobs": old,
+                "loss_mask": mask, "temperature": temp, "ratio_type": "token", "ratio_length_norm": False,
+                "clip_ratio": 8.0, "loss_scale": scale,
+                "exp_logprobs": ref["logprobs"][0], "exp_entropy": ref["entropy"][0], "exp_lengths": ref["lengths"],
+                "exp_loss": ref["loss"], "exp_importance_ratio": ref["importance_ratio"],
+                "exp_clipped_importance_ratio": ref["clipped_importance_ratio"], "exp_is_clipped": ref["is_clipped"],
+                "exp_dlogits": ref["dlogits"][0],
+                "f64_entropy": ent64, "f64_logprobs": lp64,
+            }),
+        )
+        n += 1
+    return n
+
+
 def golden_pieces(R, LossConfig) -> int:
     """Function-level vectors: shift, selective_log_softmax (fp32 and bf16
     branches), entropy and compute_loss on its own inputs."""
@@ -483,6 +535,7 @@ def main() -> None:
     must(A.compute_advantages([0.0, 0.0, 1.0, 1.0], [3, 4, 5, 6], 4, "drgrpo") == [-0.5, -0.5, 0.5, 0.5], "docstring example")
     counts = {
         "epilogue": golden_epilogue(R, grl, LossConfig),
+        "full_vocabulary": golden_full_vocabulary(R, grl, LossConfig),
         "pieces": golden_pieces(R, LossConfig),
         "lengths": golden_lengths(grl),
         "advantages": golden_advantages(A),

@@ -30,6 +30,11 @@ def epilogue_cases() -> list[str]:
     return sorted(p.name for p in GOLDEN.glob("epilogue_*.npz"))
 
 
+def full_vocabulary_cases() -> list[str]:
+    """Whole-epilogue vectors at V = 151936 / 152064, temperature 0.6, bf16 logits (a few MB each)."""
+    return sorted(p.name for p in GOLDEN.glob("full_*.npz"))
+
+
 def make_packed_row(gen: torch.Generator, lengths, pad=0, vocab=1000, mask_p=0.6):
     pos = torch.cat([torch.arange(n) for n in lengths] + [torch.zeros(pad, dtype=torch.long)])
     t = pos.shape[0]

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import ref_cpu as O
-from tests.helpers import epilogue_cases, load_npz, GOLDEN
+from tests.helpers import epilogue_cases, full_vocabulary_cases, load_npz, GOLDEN
 
 
 def same(a, b):
@@ -26,7 +26,7 @@ def _one_thread():
     torch.set_num_threads(n)
 
 
-@pytest.mark.parametrize("name", epilogue_cases())
+@pytest.mark.parametrize("name", epilogue_cases() + full_vocabulary_cases())
 def test_epilogue_matches_reference_vectors(name):
     d = load_npz(name)
     cfg = O.LossConfig(d["ratio_type"], bool(d["ratio_length_norm"]), float(d["clip_ratio"]))
@@ -42,6 +42,21 @@ def test_epilogue_matches_reference_vectors(name):
     for k in ("importance_ratio", "clipped_importance_ratio", "is_clipped"):
         assert same(out[k], d["exp_" + k]), k
     assert same(out["dlogits"][0], d["exp_dlogits"])
+
+
+@pytest.mark.parametrize("name", full_vocabulary_cases())
+def test_full_vocabulary_vectors_say_how_far_the_reference_is_from_float64(name):
+    """The float64 side of the fixture is what the generating script says it is (recomputed here from the
+    stored logits), and the reference's fp32 entropy is 1e-4 .. 4e-4 away from it at this size while its
+    log-probabilities are within 1e-5: the entropy bound of the GPU test rests on these two facts."""
+    d = load_npz(name)
+    # the fp32 quotient the reference's entropy sees (train.py:285-287), then everything in float64
+    x = (O.shift_logits(d["logits"].float().unsqueeze(0)) / float(d["temperature"])).double()
+    ent = (torch.logsumexp(x, -1) - (torch.softmax(x, -1) * x).sum(-1))[0]
+    assert torch.allclose(ent, d["f64_entropy"], rtol=0, atol=1e-12)
+    err = (d["exp_entropy"].double() - d["f64_entropy"]).abs().max().item()
+    assert 1e-4 < err < 4e-4
+    assert (d["exp_logprobs"].double() - d["f64_logprobs"]).abs().max().item() < 1e-5
 
 
 @pytest.mark.parametrize("name", sorted(p.name for p in GOLDEN.glob("pieces_*.npz")))
