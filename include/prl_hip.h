@@ -85,6 +85,23 @@ int prl_logprob_entropy_fwd(const void* logits, int logits_dtype, int64_t T, int
                             float* lse, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * prl_logprob_entropy_fwd for callers that cannot allocate device memory or hand over a workspace: code under
+ * HIP graph capture, tight serving loops that score a few tokens per call, harnesses that forbid hipMalloc.
+ * It has no counterpart in the reference.  Same arguments, same kernels and bit-identical results; the partial
+ * soft-max states of rows that are split over several workgroups (T < 1024) live in a fixed array of
+ * prl_logprob_static_scratch_bytes() = 49152 bytes of device memory that every GPU the library runs on holds
+ * until the process ends.  The call makes no hipMalloc / hipFree; a problem whose scratch would not fit the
+ * array is refused with PRL_EINVAL (no size the split rule produces today does).  The first call on a device
+ * looks the array's address up (a host-side runtime query): make it outside stream capture.  All calls on one
+ * GPU share the array, so calls that overlap on one GPU (two streams, two threads) race; calls on one stream
+ * are ordered.  Nothing in the array needs clearing between calls.
+ */
+size_t prl_logprob_static_scratch_bytes(void);
+int prl_logprob_entropy_fwd_static(const void* logits, int logits_dtype, int64_t T, int64_t V, int64_t row_stride,
+                                   const int64_t* ids, float temperature, int shift, float* logprob, float* entropy,
+                                   float* lse, void* stream);
+
+/*
  * Gradient of sum_t g[t] * logprob[t] with respect to the logits, in one pass:
  *     dlogits[r, v] = g[t]/temperature * (1[v == ids[t]] - exp(x[r,v]/temperature - lse[t])),
  *     t = r + shift.

@@ -39,6 +39,11 @@ SIGNATURES = {
         [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p,
          c_void_p, c_size_t, c_void_p],
     ),
+    "prl_logprob_static_scratch_bytes": (c_size_t, []),
+    "prl_logprob_entropy_fwd_static": (
+        c_int,
+        [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
     "prl_logprob_bwd": (
         c_int,
         [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,

@@ -7,6 +7,7 @@
 // reference chain (src/prime_rl/trainer/rl/loss.py:13-58,
 // src/prime_rl/trainer/rl/train.py:285-288) are folded into indexing and into
 // one multiply, so no shifted or scaled copy of the logits is ever written.
+#include <mutex>
 #include "logprob_dev.h"
 
 namespace prl {
@@ -282,6 +283,58 @@ extern "C" int prl_logprob_entropy_fwd(const void* logits, int logits_dtype, int
                                        size_t workspace_bytes, void* stream) {
   return logprob_fwd_impl(logits, logits_dtype, T, V, row_stride, ids, temperature, shift, nullptr, logprob, entropy,
                           lse, workspace, workspace_bytes, stream);
+}
+
+// ---------------------------------------------------------------- the entry point that allocates nothing
+//
+// Same kernels as prl_logprob_entropy_fwd; the partial soft-max states of rows split over several workgroups go
+// to a fixed array in device memory instead of a caller workspace.  Every GPU the library runs on holds its own
+// copy of the array, at its own address, until the process ends.
+constexpr size_t kStaticScratchBytes = 49152;  // 3072 partial states: T * nsplit stays below 2048 + T, T < 1024
+constexpr int kMaxDevices = 64;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+static std::mutex g_scratch_mutex;
+static void* g_scratch_ptr[kMaxDevices] = {};  // the array's device address, per device; `scratch` itself is only
+                                               // a host-side handle and must never be passed to a kernel
+
+extern "C" size_t prl_logprob_static_scratch_bytes(void) { return kStaticScratchBytes; }
+
+extern "C" int prl_logprob_entropy_fwd_static(const void* logits, int logits_dtype, int64_t T, int64_t V,
+                                              int64_t row_stride, const int64_t* ids, float temperature, int shift,
+                                              float* logprob, float* entropy, float* lse, void* stream) {
+  clear_error();
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+    (void)hipGetLastError();
+    set_error("logprob_entropy_fwd_static: no current device, or its index %d is beyond %d", dev, kMaxDevices - 1);
+    return PRL_ELAUNCH;
+  }
+  void* ptr = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    ptr = g_scratch_ptr[dev];
+    if (!ptr) {  // first call on this device: ask the runtime where this device's copy of the array lives
+      const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+      if (e != hipSuccess || !ptr) {
+        (void)hipGetLastError();
+        set_error("logprob_entropy_fwd_static: hipGetSymbolAddress failed on device %d: %s", dev,
+                  hipGetErrorString(e));
+        return PRL_ELAUNCH;
+      }
+      g_scratch_ptr[dev] = ptr;
+    }
+  }
+  const size_t need = prl_logprob_workspace_bytes(T, V);
+  if (need > kStaticScratchBytes) {
+    set_error("logprob_entropy_fwd_static: T=%lld V=%lld needs %zu bytes of scratch, the static array holds %zu; "
+              "use prl_logprob_entropy_fwd with a workspace of the caller's",
+              (long long)T, (long long)V, need, kStaticScratchBytes);
+    return PRL_EINVAL;
+  }
+  // nothing in the array has to start from zero: every partial state the merge kernel reads was written by the
+  // launch before it
+  return logprob_fwd_impl(logits, logits_dtype, T, V, row_stride, ids, temperature, shift, nullptr, logprob, entropy,
+                          lse, ptr, kStaticScratchBytes, stream);
 }
 
 // `skip`: optional 0/1 per token; tokens with 0 are not scored (their row is not read, their outputs are 0)
