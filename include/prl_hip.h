@@ -79,6 +79,13 @@ size_t prl_logprob_workspace_bytes(int64_t T, int64_t V);
  *   entropy[t] = lse[t] - sum_v softmax(x/temperature)_v * x_v/temperature
  *   lse[t]     = logsumexp(x/temperature)
  * An id outside [0, V) yields NaN in logprob[t] (torch.gather would raise).
+ *
+ * Accuracy against the reference's fp32 torch results: logprob and lse within 2e-6 at V = 152 K.  The entropy is
+ * within 1e-5 of a float64 evaluation of loss.py:43-47; at V = 152 K and temperature 0.6 that is 2.6e-4 .. 2.8e-4
+ * away from what the reference's own fp32 softmax-multiply-sum returns on the CPU, because that fp32 evaluation is
+ * itself that far from float64 there (reference-made vectors tests/golden/full_v*.npz hold both values;
+ * tests/test_gpu_config_shapes.py asserts both distances).  At the small vocabularies of the other vectors the
+ * entropy meets 1e-4 against the reference directly.
  */
 int prl_logprob_entropy_fwd(const void* logits, int logits_dtype, int64_t T, int64_t V, int64_t row_stride,
                             const int64_t* ids, float temperature, int shift, float* logprob, float* entropy,
