@@ -32,6 +32,7 @@ memory by the captured kernels, never baked into a graph.
 
 from __future__ import annotations
 
+import re
 import time
 from collections import OrderedDict
 from typing import Any
@@ -55,6 +56,59 @@ def _round_up(n: int, a: int) -> int:
     return (n + a - 1) // a * a
 
 
+_LAYER = re.compile(r"^(.*\.layers\.\d+)\.")  # parameters of one transformer block share this prefix
+
+
+def bucket_plan(names: list[str], numel: list[int], bucket_elems: int | None) -> list[tuple[int, int]]:
+    """Consecutive parameters [first, last) per exchange bucket.  A transformer block is never cut (its
+    parameters get their gradients within a few kernels of each other, and the forward needs all of them at
+    once); blocks and the parameters outside them (embedding table, final norm, an untied LM head) are joined
+    front to back while a bucket stays within `bucket_elems` elements (a group of less than 1/64 of that joins
+    the bucket before it regardless).  None: one bucket for everything."""
+    if not names:
+        return []
+    if bucket_elems is None:
+        return [(0, len(names))]
+    groups: list[list] = []  # [key, first, last, elements]
+    for i, (name, n) in enumerate(zip(names, numel)):
+        m = _LAYER.match(name)
+        key = m.group(1) if m else name
+        if groups and groups[-1][0] == key:
+            groups[-1][2] = i + 1
+            groups[-1][3] += n
+        else:
+            groups.append([key, i, i + 1, n])
+    out: list[list[int]] = []
+    for _, first, last, n in groups:
+        if out and (out[-1][2] + n <= bucket_elems or n * 64 <= bucket_elems):  # (small fry never opens a bucket)
+            out[-1][1] = last
+            out[-1][2] += n
+        else:
+            out.append([first, last, n])
+    return [(a, b) for a, b, _ in out]
+
+
+class Bucket:
+    """Parameters [first, last) of the flat buffers, elements [lo, hi); of these every rank owns `shard`
+    consecutive elements, rank r those from lo + r * shard, kept at [shard_lo, shard_lo + shard) of its master
+    shard.  One reduce-scatter of the gradient sums and one all-gather of the new compute copy per bucket
+    and step."""
+
+    __slots__ = ("index", "first", "last", "lo", "hi", "shard", "shard_lo", "reduce_work", "gather_work", "reduced",
+                 "held", "pending", "launched", "chunk_lo", "chunk_hi")
+
+    def __init__(self, index: int, first: int, last: int):
+        self.index, self.first, self.last = index, first, last
+        self.lo = self.hi = self.shard = self.shard_lo = 0
+        self.reduce_work: Any = None  # the reduce-scatter in flight (RCCL), until somebody has waited for it
+        self.gather_work: Any = None  # the all-gather in flight
+        self.reduced = False          # this step's gradient sums of the bucket have been handed to the exchange
+        self.held = False             # Replica: reduced only after the pass (the embedding table's gradient comes last)
+        self.pending = 0              # Replica: gradients of this pass still to land
+        self.launched = False
+        self.chunk_lo = self.chunk_hi = 0
+
+
 class FlatState:
     """The flat buffers of one rank and the end of a step over them (no HIP code in here: plain torch and
     torch.distributed, so it also runs on the CPU over gloo).
@@ -62,74 +116,149 @@ class FlatState:
     `flat16`  [n]      compute copy of all parameters (the model's parameters are views into it)
     `acc32`   [n]      this rank's gradient sum over the micro-batches of the step, fp32
     `master`  [n / W]  this rank's shard of the fp32 master weights (an nn.Parameter: the optimizer's only one)
+
+    The buffers are cut into buckets (`bucket_plan`).  Every bucket is sharded over the ranks by itself, so that
+    a bucket's gradient sums can be reduce-scattered as soon as backward has produced them, while backward goes on
+    (the reference gets the same overlap from FSDP2's per-block groups, src/prime_rl/trainer/model.py:102-135),
+    and its new weights can be all-gathered while the next forward is already running on earlier buckets.  The
+    master shard is the concatenation of the rank's parts of all buckets.  With one bucket (the default) the
+    layout is "rank r owns elements [r * n / W, (r + 1) * n / W)".  AdamW and SGD are element-wise, and every
+    element's gradient is the same sum over ranks whatever bucket it is in, so bucketing changes no value.
     """
 
-    def __init__(self, model: nn.Module, group: Any = None, compute_dtype: torch.dtype = torch.bfloat16):
+    def __init__(self, model: nn.Module, group: Any = None, compute_dtype: torch.dtype = torch.bfloat16,
+                 bucket_bytes: int | None = None, exchange_alone: bool = False):
+        """`bucket_bytes`: target size of a bucket's fp32 gradient sums (None: one bucket).  `exchange_alone`:
+        a single rank still goes through the collectives (over its one-member group), for tests of that path."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.params = list(model.parameters())
+        self.exchange = self.world > 1 or (exchange_alone and dist.is_initialized())
+        named = list(model.named_parameters())
+        self.names = [n for n, _ in named]
+        self.params = [p for _, p in named]
         if not self.params:
             raise ValueError("FlatState: the model has no parameters")
         dev = self.params[0].device
         self.numel = [p.numel() for p in self.params]
-        self.offsets, off = [], 0
-        for n in self.numel:
-            self.offsets.append(off)
-            off += _round_up(n, ALIGN)
-        self.total = _round_up(off, ALIGN * self.world)
+        plan = bucket_plan(self.names, self.numel, None if bucket_bytes is None else max(int(bucket_bytes) // 4, 1))
+        self.buckets = [Bucket(k, a, b) for k, (a, b) in enumerate(plan)]
+        self.bucket_of = [0] * len(self.params)
+        self.offsets, off, shard_lo = [], 0, 0
+        for b in self.buckets:
+            b.lo = off
+            for i in range(b.first, b.last):
+                self.bucket_of[i] = b.index
+                self.offsets.append(off)
+                off += _round_up(self.numel[i], ALIGN)
+            off = b.lo + _round_up(off - b.lo, ALIGN * self.world)
+            b.hi = off
+            b.shard = (b.hi - b.lo) // self.world
+            b.shard_lo = shard_lo
+            shard_lo += b.shard
+        self.total = off
         self.shard = self.total // self.world
-        lo, hi = self.rank * self.shard, (self.rank + 1) * self.shard
         self.flat16 = torch.zeros(self.total, dtype=compute_dtype, device=dev)
         master = torch.zeros(self.shard, dtype=torch.float32, device=dev)
-        for p, o, n in zip(self.params, self.offsets, self.numel):
+        for i, (p, o, n) in enumerate(zip(self.params, self.offsets, self.numel)):
             src = p.detach().reshape(-1)
             self.flat16[o : o + n].copy_(src)
-            a, b = max(o, lo), min(o + n, hi)
-            if a < b:
-                master[a - lo : b - lo].copy_(src[a - o : b - o])
+            b = self.buckets[self.bucket_of[i]]
+            lo = b.lo + self.rank * b.shard  # this rank's part of the bucket, in flat coordinates
+            a, z = max(o, lo), min(o + n, lo + b.shard)
+            if a < z:
+                master[b.shard_lo + a - lo : b.shard_lo + z - lo].copy_(src[a - o : z - o])
             p.data = self.flat16[o : o + n].view(p.shape)  # the fp32 original is released here
         self.master = nn.Parameter(master)
         self.acc32 = torch.zeros(self.total, dtype=torch.float32, device=dev)
-        self._shard_grad = torch.zeros(self.shard, dtype=torch.float32, device=dev) if self.world > 1 else None
-        self._shard16 = torch.zeros(self.shard, dtype=compute_dtype, device=dev) if self.world > 1 else None
+        self._shard_grad = torch.zeros(self.shard, dtype=torch.float32, device=dev) if self.exchange else None
+        self._shard16 = torch.zeros(self.shard, dtype=compute_dtype, device=dev) if self.exchange else None
 
     def holder(self) -> nn.Module:
         """A module whose only parameter is the master shard: what the optimizer is built over.  AdamW and SGD
         are element-wise, so one flat parameter takes exactly the steps the separate parameters would."""
         return nn.ParameterList([self.master])
 
+    def owned_ranges(self) -> list[tuple[int, int, int]]:
+        """(flat_lo, flat_hi, master_lo) of every stretch of the flat buffers whose master weights this rank holds."""
+        return [(b.lo + self.rank * b.shard, b.lo + (self.rank + 1) * b.shard, b.shard_lo) for b in self.buckets]
+
     def _gloo(self) -> bool:
         return dist.is_initialized() and dist.get_backend(self.group) == "gloo"
 
-    def _gather_compute_copy(self) -> None:
-        """Every rank's new shard of the compute copy into every rank's `flat16`."""
-        if self._gloo():  # gloo gets host tensors only
-            parts = [torch.empty(self.shard, dtype=self.flat16.dtype) for _ in range(self.world)]
-            dist.all_gather(parts, self._shard16.cpu(), group=self.group)
-            self.flat16.copy_(torch.cat(parts))
-        else:
-            dist.all_gather_into_tensor(self.flat16, self._shard16, group=self.group)
+    # ------------------------------------------------------------------ the exchange, bucket by bucket
 
-    def finish_step(self, optimizer: torch.optim.Optimizer, max_norm: float | None, keep_sums: bool = False) -> Tensor:
+    def reduce_bucket(self, b: Bucket) -> None:
+        """Mean over the ranks of bucket `b`'s gradient sums, this rank's part of it into its gradient shard.
+        Over RCCL the reduce-scatter is started behind what the current stream holds so far and left in
+        flight (`wait_reduced` makes the current stream wait for it); over gloo it is done on return."""
+        if not self.exchange or b.reduced:
+            return
+        b.reduced = True
+        grad = self._shard_grad[b.shard_lo : b.shard_lo + b.shard]
+        sums = self.acc32[b.lo : b.hi]
+        if self._gloo():  # no reduce-scatter in gloo, host tensors only: reduce the bucket, keep the own part
+            total = sums.cpu()
+            dist.all_reduce(total, group=self.group)
+            grad.copy_(total[self.rank * b.shard : (self.rank + 1) * b.shard]).div_(self.world)
+        else:
+            b.reduce_work = dist.reduce_scatter_tensor(grad, sums, op=dist.ReduceOp.AVG, group=self.group,
+                                                       async_op=True)
+
+    def wait_reduced(self) -> None:
+        """Every bucket reduced (those nobody has started are started here) and the current stream behind all of it."""
+        for b in self.buckets:
+            self.reduce_bucket(b)
+        for b in self.buckets:
+            if b.reduce_work is not None:
+                b.reduce_work.wait()
+                b.reduce_work = None
+
+    def _gather_compute_copy(self) -> None:
+        """Every rank's new part of every bucket of the compute copy into every rank's `flat16`: one all-gather
+        per bucket, front to back, over RCCL left in flight (`wait_gathered`)."""
+        for b in self.buckets:
+            part = self._shard16[b.shard_lo : b.shard_lo + b.shard]
+            if self._gloo():  # gloo gets host tensors only
+                parts = [torch.empty(b.shard, dtype=self.flat16.dtype) for _ in range(self.world)]
+                dist.all_gather(parts, part.cpu(), group=self.group)
+                self.flat16[b.lo : b.hi].copy_(torch.cat(parts))
+            else:
+                b.gather_work = dist.all_gather_into_tensor(self.flat16[b.lo : b.hi], part, group=self.group,
+                                                            async_op=True)
+
+    def wait_gathered(self, b: Bucket | None = None) -> None:
+        """The current stream waits until bucket `b` (None: every bucket) of `flat16` holds the new weights."""
+        for x in (self.buckets if b is None else (b,)):
+            if x.gather_work is not None:
+                x.gather_work.wait()
+                x.gather_work = None
+
+    def finish_step(self, optimizer: torch.optim.Optimizer, max_norm: float | None, keep_sums: bool = False,
+                    gathers_in_flight: bool = False) -> Tensor:
         """Mean of the ranks' gradient sums, clip by the global norm, optimizer step on the shard, new compute
         copy on every rank.  Returns the gradient norm before clipping (a 0-d tensor on the device; reading it
         is the caller's one host synchronisation).  Same clipping rule as torch.nn.utils.clip_grad_norm_,
         which the reference calls (src/prime_rl/trainer/rl/train.py:336-338).  `keep_sums` leaves the gradient
-        sums as they are (for a caller whose next step overwrites them); otherwise they are cleared."""
-        if self.world > 1:
+        sums as they are (for a caller whose next step overwrites them); otherwise they are cleared.  Buckets
+        whose reduction a caller has already started (`reduce_bucket`) are only waited for.  With
+        `gathers_in_flight` the all-gathers of the new compute copy (RCCL) are left running and it is the caller
+        who makes a stream wait for a bucket before reading it (`wait_gathered`)."""
+        try:
+            return self._finish_step(optimizer, max_norm, keep_sums)
+        finally:
+            if not gathers_in_flight:
+                self.wait_gathered()
+
+    def _finish_step(self, optimizer: torch.optim.Optimizer, max_norm: float | None, keep_sums: bool) -> Tensor:
+        self.wait_gathered()  # (a step without any forward: the last step's weights must have arrived)
+        if self.exchange:
+            self.wait_reduced()
             grad = self._shard_grad
-            if self._gloo():  # no reduce-scatter in gloo: reduce everything (on the host), keep the own part
-                total = self.acc32.cpu()
-                dist.all_reduce(total, group=self.group)
-                lo = self.rank * self.shard
-                grad.copy_(total[lo : lo + self.shard]).div_(self.world)
-            else:
-                dist.reduce_scatter_tensor(grad, self.acc32, op=dist.ReduceOp.AVG, group=self.group)
         else:
             grad = self.acc32
         sq = torch.linalg.vector_norm(grad, 2, dtype=torch.float32).square()
-        if self.world > 1:
+        if self.exchange:
             if self._gloo():
                 host = sq.cpu()
                 dist.all_reduce(host, group=self.group)
@@ -138,9 +267,11 @@ class FlatState:
                 dist.all_reduce(sq, group=self.group)
         norm = sq.sqrt()
         coef = torch.clamp(max_norm / (norm + 1e-6), max=1.0).reshape(1) if max_norm is not None else None
+        for b in self.buckets:
+            b.reduced = False
         if hasattr(optimizer, "step_flat"):
             # clipping, the update, the new compute copy and (one rank) the clearing of the sums in one launch
-            if self.world > 1:
+            if self.exchange:
                 optimizer.step_flat(grad, coef, self._shard16)
                 self._gather_compute_copy()
                 if not keep_sums:
@@ -153,7 +284,7 @@ class FlatState:
         self.master.grad = grad
         optimizer.step()
         self.master.grad = None
-        if self.world > 1:
+        if self.exchange:
             self._shard16.copy_(self.master.detach())
             self._gather_compute_copy()
         else:
@@ -161,6 +292,12 @@ class FlatState:
         if not keep_sums:
             self.acc32.zero_()
         return norm
+
+
+def ctypes_ptr(t: Tensor, byte_offset: int = 0) -> Any:
+    import ctypes
+
+    return ctypes.c_void_p(t.data_ptr() + byte_offset)
 
 
 class GraphHoldsMemsets(RuntimeError):
@@ -199,12 +336,23 @@ class Replica:
     """The training side of one rank: model, flat state, optimizer and the micro-batch graphs."""
 
     def __init__(self, model: nn.Module, optimizer_factory: Any, group: Any = None, graphs: bool = False,
-                 max_graphs: int = 4, compute_dtype: torch.dtype = torch.bfloat16):
+                 max_graphs: int = 4, compute_dtype: torch.dtype = torch.bfloat16,
+                 bucket_bytes: int | None = -1, exchange_alone: bool = False):
         """`model` on the GPU in any floating dtype (its values seed the fp32 master weights);
         `optimizer_factory(module)` builds the optimizer over `module.parameters()`; `compute_dtype` is what
-        FSDP2's `param_dtype` is in the reference (bf16; fp32 for exact comparisons)."""
+        FSDP2's `param_dtype` is in the reference (bf16; fp32 for exact comparisons).  `bucket_bytes`: size of
+        the buckets the gradient exchange is cut into, in bytes of fp32 gradient sums (-1: PRL_BUCKET_MB, 256 MB
+        when unset; None: one bucket, exchanged after the pass); with more than one rank and more than one
+        bucket the last pass of a step reduce-scatters every bucket while backward is still running."""
+        import os
+
         self.model = model
-        self.state = FlatState(model, group, compute_dtype)
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if bucket_bytes == -1:
+            bucket_bytes = int(float(os.environ.get("PRL_BUCKET_MB", "256")) * 2**20) or None
+        if graphs or not (world > 1 or exchange_alone):
+            bucket_bytes = None  # a captured pass is one launch; a single rank exchanges nothing
+        self.state = FlatState(model, group, compute_dtype, bucket_bytes, exchange_alone)
         self.device = self.state.flat16.device
         if self.device.type != "cuda":
             raise RuntimeError("Replica: the model must be on a GPU (there is no CPU path)")
@@ -237,6 +385,24 @@ class Replica:
         self._numel = torch.tensor(st.numel, dtype=torch.int64).to(self.device)
         self._offsets = torch.tensor(st.offsets, dtype=torch.int64).to(self.device)
         unit_gradient(self.device)  # exists before any capture
+        # the exchange overlapped with backward: which chunks belong to which bucket, and the hooks that tell
+        # when a bucket's last gradient has landed / when a module is about to read a bucket's weights
+        n_chunks = np.cumsum([0] + [len(x) for x in tensor_of])
+        for b in st.buckets:
+            b.chunk_lo, b.chunk_hi = int(n_chunks[b.first]), int(n_chunks[b.last])
+        self.overlap = st.exchange and len(st.buckets) > 1 and not graphs
+        self._overlapping = False  # inside the last pass of a step
+        self._first_form = False
+        self._next_bucket = -1
+        self._src = torch.zeros(len(st.params), dtype=torch.int64, device=self.device)
+        self.bucket_launches = 0  # buckets handed to the exchange from inside a backward pass
+        if self.overlap:
+            table = self.model.get_input_embeddings().weight
+            for i, prm in enumerate(st.params):
+                if prm is table:
+                    st.buckets[st.bucket_of[i]].held = True
+                prm.register_post_accumulate_grad_hook(lambda _p, i=i: self._gradient_landed(i))
+            self._hook_weight_arrival()
 
     # ------------------------------------------------------------------ one micro-batch
 
@@ -265,10 +431,118 @@ class Replica:
         grads = [p.grad for p in self.state.params]
         return loss.detach(), aux, grads, rows.grad
 
-    def _grad_pointers(self, grads: list) -> list[int]:
+    # ------------------------------------------------------------------ the exchange inside backward
+
+    def _hook_weight_arrival(self) -> None:
+        """A forward pre-hook on every module that is the largest one living in a single bucket (a transformer
+        block, the embedding, the final norm, the LM head): before it runs, the stream waits for that bucket's
+        all-gather of the previous step.  Later buckets are then still arriving while earlier ones compute."""
+        st = self.state
+        index = {id(p): st.bucket_of[i] for i, p in enumerate(st.params)}
+        spans: dict[int, set[int]] = {}
+
+        def span(m: nn.Module) -> set[int]:
+            if id(m) not in spans:
+                out = {index[id(p)] for p in m.parameters(recurse=False) if id(p) in index}
+                for c in m.children():
+                    out |= span(c)
+                spans[id(m)] = out
+            return spans[id(m)]
+
+        def wait_for(which: list[int]) -> Any:
+            def hook(_module: nn.Module, _args: Any) -> None:
+                for k in which:
+                    st.wait_gathered(st.buckets[k])
+
+            return hook
+
+        def walk(m: nn.Module) -> None:
+            mine = span(m)
+            if not mine:
+                return
+            if len(mine) == 1:
+                m.register_forward_pre_hook(wait_for(sorted(mine)))
+                return
+            own = {index[id(p)] for p in m.parameters(recurse=False) if id(p) in index}
+            if own:  # a module that spans buckets and has parameters of its own
+                m.register_forward_pre_hook(wait_for(sorted(own)))
+            for c in m.children():
+                walk(c)
+
+        walk(self.model)
+
+    def _gradient_landed(self, i: int) -> None:
+        """Post-accumulate hook of parameter `i` (runs on autograd's thread, on the stream of the pass).  Buckets
+        go to the exchange back to front, each only after all behind it, so that every rank issues the same
+        collectives in the same order whatever order its gradients land in."""
+        if not self._overlapping:
+            return
+        st = self.state
+        st.buckets[st.bucket_of[i]].pending -= 1
+        while self._next_bucket >= 0:
+            b = st.buckets[self._next_bucket]
+            if b.held:
+                self._next_bucket -= 1
+                continue
+            if b.pending > 0:
+                break
+            self._launch_bucket(b)
+            self.bucket_launches += 1
+            self._next_bucket -= 1
+
+    def _launch_bucket(self, b: Bucket, reduce: bool = True) -> None:
+        """Bucket `b`'s fresh gradients into the flat sums (one launch over the bucket's chunks) and, behind that
+        launch, its reduce-scatter; the gradients themselves are dropped."""
+        st = self.state
+        params = st.params[b.first : b.last]
+        ptrs = self._grad_pointers([p.grad for p in params], params)
+        self._src[b.first : b.last].copy_(torch.tensor(ptrs, dtype=torch.int64).pin_memory(), non_blocking=True)
+        lib = C.load()
+        entry = lib.prl_accumulate_first if self._first_form else lib.prl_accumulate
+        item32, item64 = self._chunk_tensor.element_size(), self._chunk_start.element_size()
+        with C.on_device(self.device):
+            C.check(
+                entry(C.ptr(self._src), C.dtype_code(st.flat16), C.ptr(self._offsets), C.ptr(self._numel),
+                      ctypes_ptr(self._chunk_tensor, b.chunk_lo * item32), ctypes_ptr(self._chunk_start, b.chunk_lo * item64),
+                      b.chunk_hi - b.chunk_lo, C.ptr(self._scale), C.ptr(st.acc32), C.stream_ptr(self.device)),
+                "prl_accumulate",
+            )
+        b.launched = True
+        for p in params:
+            p.grad = None
+        if reduce:
+            st.reduce_bucket(b)
+
+    def _begin_overlapped_pass(self) -> None:
+        self._overlapping = True
+        self._first_form = self._starts_sums
+        self._starts_sums = False
+        self._next_bucket = len(self.state.buckets) - 1
+        for b in self.state.buckets:
+            b.launched = False
+            b.pending = sum(1 for p in self.state.params[b.first : b.last] if p.requires_grad)
+
+    def _end_overlapped_pass(self, input_ids: Tensor, embed_grad: Tensor) -> None:
+        """What backward's hooks have not started: buckets with a parameter that got no gradient, and the bucket
+        of the embedding table, whose second share (the looked-up rows' gradient) only exists now."""
+        self._overlapping = False
+        st = self.state
+        for b in reversed(st.buckets):
+            if not b.launched and not b.held:
+                self._launch_bucket(b)
+        for b in st.buckets:
+            if b.held and not b.launched:
+                self._launch_bucket(b, reduce=False)
+        self._embedding_backward(input_ids, embed_grad)
+        for b in st.buckets:
+            if b.held:
+                st.reduce_bucket(b)
+        self._first_form = False
+
+    def _grad_pointers(self, grads: list, params: list | None = None) -> list[int]:
         dt = self.state.flat16.dtype
         ptrs = []
-        for g, p in zip(grads, self.state.params):
+        for g, p in zip(grads, self.state.params if params is None else params):
             if g is None:
                 ptrs.append(0)
                 continue
@@ -345,9 +619,12 @@ class Replica:
         cap.src.copy_(torch.tensor(ptrs, dtype=torch.int64))
         return cap
 
-    def micro_batch(self, mb: dict[str, Any], plan: Any, loss_config: LossConfig) -> tuple[Tensor, dict[str, Tensor]]:
+    def micro_batch(self, mb: dict[str, Any], plan: Any, loss_config: LossConfig, last: bool = False
+                    ) -> tuple[Tensor, dict[str, Tensor]]:
         """Forward, loss, backward and gradient accumulation of one row that is already on the device.
-        Returns the loss (for normaliser 1) and the per-token results, all safe to keep."""
+        Returns the loss (for normaliser 1) and the per-token results, all safe to keep.  `last`: no other pass
+        follows in this step, so every bucket's gradient sums are final once its gradients have landed and
+        (with several ranks) go to the exchange from inside backward."""
         key = self._key(mb, plan, loss_config)
         cap = self._captured.get(key)
         if cap is None and self.graphs and key in self._seen and key not in self.capture_errors:
@@ -379,6 +656,18 @@ class Replica:
             self._embedding_backward(cap.inputs["input_ids"], cap.embed_grad)
             self.replays += 1
             return cap.loss.clone(), {k: cap.aux[k].clone() for k in _AUX_KEYS}
+        if self.overlap and last:
+            self._begin_overlapped_pass()
+            try:
+                loss, aux, grads, embed_grad = self._forward_backward(mb, plan, loss_config)
+            finally:
+                self._overlapping = False
+            del grads
+            self._end_overlapped_pass(mb["input_ids"], embed_grad)
+            del embed_grad
+            self._drop_grads()
+            self.eager_runs += 1
+            return loss, aux
         loss, aux, grads, embed_grad = self._forward_backward(mb, plan, loss_config)
         src = host_to_device(self._grad_pointers(grads), self.device, torch.int64)
         self._accumulate(src, first=self._starts_sums)
@@ -388,6 +677,11 @@ class Replica:
         self._drop_grads()
         self.eager_runs += 1
         return loss, aux
+
+    def wait_parameters(self) -> None:
+        """The current stream waits for every all-gather still in flight: call before reading the model's
+        parameters outside a forward pass (publishing weights, snapshots)."""
+        self.state.wait_gathered()
 
     # ------------------------------------------------------------------ one optimizer step
 
@@ -423,7 +717,8 @@ class Replica:
         vocab = int(self.model.config.vocab_size)
         for step_idx, host_mb in enumerate(units):
             mb = to_device(host_mb, self.device)
-            loss, aux = self.micro_batch(mb, attention_plan(host_mb, self.device), loss_config)
+            loss, aux = self.micro_batch(mb, attention_plan(host_mb, self.device), loss_config,
+                                         last=step_idx == len(units) - 1)
             if rows is not None:
                 losses = restore_row_starts(rows[step_idx], mb, aux, loss_config, vocab, inv_scale)
                 mask = host_to_device(rows[step_idx].loss_mask, self.device)
@@ -439,7 +734,10 @@ class Replica:
             tokens += int(mb["input_ids"].numel()) - (rows[step_idx].padding if rows is not None else 0)
         if n_given > len(micro_batches):  # every filler left out: a loss of 0, as the reference logs for it
             tensors.add("loss", torch.zeros(n_given - len(micro_batches), dtype=torch.float32, device=self.device))
-        grad_norm = self.state.finish_step(self.optimizer, max_norm, keep_sums=not self.graphs)
+        if not units:  # nothing was scored on this rank: its share of the mean is zero, not last step's sums
+            self.state.acc32.zero_()
+        grad_norm = self.state.finish_step(self.optimizer, max_norm, keep_sums=not self.graphs,
+                                           gathers_in_flight=self.overlap)
         if scheduler is not None:
             scheduler.step()
         stats = tensors.compute_stats()

@@ -210,6 +210,8 @@ def _train(config: RLTrainerConfig, world: Any, device: torch.device, mesh: Any)
         t_step = time.perf_counter()
         torch.cuda.reset_peak_memory_stats(device)  # the step's own peak, as src/prime_rl/trainer/rl/train.py:159
         t_save = 0.0
+        if replica is not None:
+            replica.wait_parameters()  # (all-gathers of the last step's weights may still be in flight)
         if step > 0 and publish:  # weights of step N go to the inference side while step N + 1 trains
             t0 = time.perf_counter()
             publisher.publish(model, step)
@@ -263,6 +265,8 @@ def _train(config: RLTrainerConfig, world: Any, device: torch.device, mesh: Any)
             f"Throughput: {row['perf/throughput']:.0f} tokens/s | MFU: {row['perf/mfu']:.1f}% | "
             f"Peak Mem.: {row['perf/peak_memory']:.1f} GiB")
         step += 1
+    if replica is not None:
+        replica.wait_parameters()
     if step > 0 and publish:  # the final weights, as the orchestrator waits for them
         publisher.publish(model, step)
     publisher.wait_all()

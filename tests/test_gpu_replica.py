@@ -322,7 +322,11 @@ def test_eligibility():
     assert "checkpointing" in eligible(model, "adamw", activation_checkpointing=True)
 
 
-def _replica_rank(rank, world, port, q, seed):
+def _param_steps(before, model):
+    return torch.cat([(b - p.detach()).reshape(-1) for b, p in zip(before, model.parameters())])
+
+
+def _replica_rank(rank, world, port, q, seed, bucket_bytes):
     """One of two ranks that share the GPU and exchange over gloo (through host memory): a step of `Replica` on
     this rank's own micro-batches."""
     import os
@@ -339,34 +343,43 @@ def _replica_rank(rank, world, port, q, seed):
         gen = torch.Generator().manual_seed(seed + rank)
         mbs = rows(gen, 2 + rank, [24, 8, 32], 4096)  # the ranks hold different numbers of rows and of tokens
         model = T.get_model(tiny_config(vocab=4096), DEV, torch.float32, seed=11)
-        rep = Replica(model, lambda m: torch.optim.SGD(m.parameters(), lr=1.0), compute_dtype=torch.float32)
-        before = rep.state.flat16.clone()
-        res = rep.train_step(mbs, prl.LossConfig(), max_norm=1e9)
+        rep = Replica(model, lambda m: torch.optim.SGD(m.parameters(), lr=1.0), compute_dtype=torch.float32,
+                      bucket_bytes=bucket_bytes)
+        before = [p.detach().clone() for p in model.parameters()]
+        # rows kept apart (join_tokens=0): several passes, of which only the last hands buckets to the exchange
+        res = rep.train_step(mbs, prl.LossConfig(), max_norm=1e9, join_tokens=0 if bucket_bytes else None)
         # a numpy array travels by value (a torch tensor would travel as a file descriptor this process must
         # outlive)
-        q.put((rank, (before - rep.state.flat16).cpu().numpy(), res.grad_norm, res.stats["loss/mean"],
-               res.stats["entropy/mean"]))
+        q.put((rank, _param_steps(before, model).cpu().numpy(), res.grad_norm, res.stats["loss/mean"],
+               res.stats["entropy/mean"], len(rep.state.buckets), rep.bucket_launches))
+    except BaseException as e:
+        q.put((rank, repr(e)))
+        raise
     finally:
         dist.destroy_process_group()
 
 
-def test_two_ranks_take_the_mean_of_their_own_steps():
+@pytest.mark.parametrize("bucket_bytes", [None, 4 * 40000])
+def test_two_ranks_take_the_mean_of_their_own_steps(bucket_bytes):
     """Data parallel over two ranks (gloo, sharing the one GPU): every rank normalises its loss by its OWN unmasked
     tokens (src/prime_rl/trainer/rl/train.py:263-267), the gradients are averaged over the ranks, each rank updates
     its shard of the master weights and all ranks end with the same whole model.  With SGD at rate 1 the step IS the
-    gradient: it must be the mean of the two steps each rank's data gives on a single rank."""
+    gradient: it must be the mean of the two steps each rank's data gives on a single rank.  With `bucket_bytes`
+    the exchange is cut into buckets (the embedding table, every block) that are reduced from inside the last
+    backward pass of the step, as soon as their gradients have landed."""
     import torch.multiprocessing as mp
 
     seed = 77
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_replica_rank, args=(r, 2, 29741, q, seed)) for r in range(2)]
+    procs = [ctx.Process(target=_replica_rank, args=(r, 2, 29741 + (1 if bucket_bytes else 0), q, seed, bucket_bytes))
+             for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=180) for _ in procs]
     for p in procs:
         p.join(timeout=60)
-        assert p.exitcode == 0
+        assert p.exitcode == 0, results
     results = sorted(((r, torch.from_numpy(step), *rest) for r, step, *rest in results), key=lambda x: x[0])
     alone, losses = [], []
     for rank in range(2):
@@ -374,15 +387,58 @@ def test_two_ranks_take_the_mean_of_their_own_steps():
         mbs = rows(gen, 2 + rank, [24, 8, 32], 4096)
         model = T.get_model(tiny_config(vocab=4096), DEV, torch.float32, seed=11)
         rep = Replica(model, lambda m: torch.optim.SGD(m.parameters(), lr=1.0), compute_dtype=torch.float32)
-        before = rep.state.flat16.clone()
-        res = rep.train_step(mbs, prl.LossConfig(), max_norm=1e9)
-        alone.append((before - rep.state.flat16).cpu())
+        before = [p.detach().clone() for p in model.parameters()]
+        res = rep.train_step(mbs, prl.LossConfig(), max_norm=1e9, join_tokens=0 if bucket_bytes else None)
+        alone.append(_param_steps(before, model).cpu())
         losses += [res.stats["loss/mean"]] * (2 + rank)
     want = 0.5 * (alone[0] + alone[1])
-    n = want.numel()
-    for rank, step, norm, loss, entropy in results:
+    for rank, step, norm, loss, entropy, n_buckets, launched in results:
         # steps read off as differences of fp32 weights: absolute accuracy is an ulp of a weight, not of a step
-        torch.testing.assert_close(step[:n], want, rtol=1e-4, atol=1e-5 * want.abs().max().item())
+        torch.testing.assert_close(step, want, rtol=1e-4, atol=1e-5 * want.abs().max().item())
         assert norm == pytest.approx(want.norm().item(), rel=1e-4)
         assert loss == pytest.approx(sum(losses) / len(losses), rel=1e-4, abs=1e-7)  # mean over both ranks' rows
+        if bucket_bytes:  # the table's bucket waits for the looked-up rows' gradient; the blocks' went out in backward
+            assert n_buckets == 3 and launched == 2
+        else:
+            assert n_buckets == 1 and launched == 0
     assert torch.equal(results[0][1], results[1][1]) and results[0][4] == results[1][4]
+
+
+def test_exchange_inside_backward_over_rccl_leaves_the_single_rank_step_unchanged(monkeypatch):
+    """The overlapped exchange with real RCCL calls: one rank is all this box has, so the communicator has one
+    member, but every reduce-scatter and all-gather is issued for real, in flight behind the pass's stream, from
+    autograd's hooks, and waited for by the next forward's pre-hooks.  Three AdamW steps (rows apart and joined)
+    must leave exactly the weights of the plain single-rank trainer."""
+    import torch.distributed as dist
+
+    from prime_rl_cse_amd.optim import FlatAdamW
+
+    gen = torch.Generator().manual_seed(41)
+    batches = [rows(gen, 3, [32, 32, 32, 32], 4096) for _ in range(3)]
+    loss_cfg = prl.LossConfig()
+
+    def run(**kw):
+        model = T.get_model(tiny_config(vocab=4096), DEV, torch.float32, seed=11)
+        rep = Replica(model, lambda m: FlatAdamW(m.parameters(), lr=1e-3, weight_decay=0.01), **kw)
+        out = []
+        for i, mbs in enumerate(batches):
+            res = rep.train_step(mbs, loss_cfg, max_norm=1.0, join_tokens=0 if i == 1 else None)
+            rep.wait_parameters()
+            out.append((res.grad_norm, res.stats["loss/mean"], [p.detach().clone() for p in model.parameters()]))
+        return rep, out
+
+    plain, want = run()
+    for k, v in dict(MASTER_ADDR="127.0.0.1", MASTER_PORT="29745", RANK="0", WORLD_SIZE="1").items():
+        monkeypatch.setenv(k, v)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        rep, got = run(bucket_bytes=4 * 40000, exchange_alone=True)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    assert rep.overlap and len(rep.state.buckets) == 3 and rep.bucket_launches == 2 * 3
+    assert not plain.overlap and plain.bucket_launches == 0
+    for (n0, l0, p0), (n1, l1, p1) in zip(want, got):
+        assert n1 == pytest.approx(n0, rel=1e-6) and l1 == pytest.approx(l0, rel=1e-6, abs=1e-9)
+        for a, b in zip(p0, p1):
+            torch.testing.assert_close(b, a, rtol=1e-6, atol=1e-8)

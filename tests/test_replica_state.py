@@ -120,3 +120,123 @@ def test_two_ranks_shard_master_weights_and_agree_over_gloo():
     state = FlatState(model)
     for w, o in zip(want, state.offsets):
         torch.testing.assert_close(full[o : o + w.numel()].view(w.shape), w, rtol=1e-5, atol=1e-6)
+
+
+# --------------------------------------------------------------------------- the exchange in buckets
+
+
+class Blocks(nn.Module):
+    """Named like a causal LM: an embedding, numbered blocks, a final norm, a tied head."""
+
+    def __init__(self, n_layers: int = 5):
+        super().__init__()
+        self.model = nn.Module()
+        self.model.embed_tokens = nn.Embedding(53, 24)
+        self.model.layers = nn.ModuleList()
+        for _ in range(n_layers):
+            block = nn.Module()
+            block.attn = nn.Linear(24, 24, bias=False)
+            block.mlp = nn.Linear(24, 31)
+            block.norm = nn.LayerNorm(24)
+            self.model.layers.append(block)
+        self.model.norm = nn.LayerNorm(24)
+        self.lm_head = nn.Linear(24, 53, bias=False)
+        self.lm_head.weight = self.model.embed_tokens.weight
+
+
+def test_bucket_plan_keeps_blocks_whole():
+    from prime_rl_cse_amd.replica import bucket_plan
+
+    model = Blocks()
+    names = [n for n, _ in model.named_parameters()]
+    numel = [p.numel() for _, p in model.named_parameters()]
+    per_block = 24 * 24 + 24 * 31 + 31 + 48
+    assert bucket_plan(names, numel, None) == [(0, len(names))]
+    plan = bucket_plan(names, numel, 2 * per_block)
+    # the embedding table (53 * 24 elements) with the first block, two blocks, two blocks with the final norm
+    # (too small to open a bucket of its own)
+    assert plan == [(0, 6), (6, 16), (16, 28)]
+    # a bucket size smaller than anything: every block, and every parameter outside the blocks, by itself
+    assert [b - a for a, b in bucket_plan(names, numel, 1)] == [1, 5, 5, 5, 5, 5, 1, 1]
+    # the dimensions of Qwen3-0.6B at 256 MB of fp32 sums per bucket: the table, then four blocks at a time
+    names = ["model.embed_tokens.weight"] + [f"model.layers.{i}.w{j}" for i in range(28) for j in range(3)] \
+        + ["model.norm.weight"]
+    numel = [151936 * 1024] + [15_000_000, 700_000, 30_000] * 28 + [1024]
+    assert [b - a for a, b in bucket_plan(names, numel, 2**26)] == [1] + [12] * 6 + [13]
+
+
+def _bucketed_rank(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out = {}
+        for max_norm in (1e9, 0.5):  # without and with clipping
+            states = []
+            for bucket_bytes in (None, 4 * 1600):
+                torch.manual_seed(0)
+                model = Blocks()
+                state = FlatState(model, compute_dtype=torch.float32, bucket_bytes=bucket_bytes)
+                opt = torch.optim.AdamW(state.holder().parameters(), lr=1e-2, weight_decay=0.01)
+                grads = _grads(20 + rank, model)
+                norms, means = [], []
+                for s in range(3):
+                    for g, o, n in zip(grads, state.offsets, state.numel):
+                        state.acc32[o : o + n] += g.reshape(-1) * (s + 1)
+                    if bucket_bytes is not None and s == 1:
+                        # as backward's hooks do it: buckets handed over early, back to front, the first one last
+                        for b in reversed(state.buckets[1:]):
+                            state.reduce_bucket(b)
+                    state.wait_reduced()
+                    mean = torch.zeros(state.total)
+                    for lo, hi, at in state.owned_ranges():
+                        mean[lo:hi] = state._shard_grad[at : at + hi - lo]
+                    means.append(mean)
+                    norms.append(float(state.finish_step(opt, max_norm)))
+                states.append((state, model, norms, means))
+            (one, m1, norms1, means1), (many, m2, norms2, means2) = states
+            assert len(one.buckets) == 1 and len(many.buckets) > 3
+            assert many.shard * world == many.total and sum(b.shard for b in many.buckets) == many.shard
+            for a, b in zip(means1, means2):  # this rank's elements of the mean gradient, wherever they live
+                for (o1, n1), (o2, n2) in zip(zip(one.offsets, one.numel), zip(many.offsets, many.numel)):
+                    x, y = a[o1 : o1 + n1], b[o2 : o2 + n2]
+                    both = (x != 0) & (y != 0)  # (each layout gives this rank other elements)
+                    assert torch.equal(x[both], y[both])
+            same_weights = all(torch.equal(p1, p2) for p1, p2 in zip(m1.parameters(), m2.parameters()))
+            close = all(torch.allclose(p1, p2, rtol=1e-6, atol=1e-7) for p1, p2 in zip(m1.parameters(), m2.parameters()))
+            # master shard against the compute copy (fp32 here): the same numbers
+            for lo, hi, at in many.owned_ranges():
+                assert torch.equal(many.master.detach()[at : at + hi - lo], many.flat16[lo:hi])
+            out[max_norm] = (norms1, norms2, same_weights, close)
+        q.put((rank, out))
+    except BaseException as e:  # the parent should see the failure, not a time-out
+        q.put((rank, repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_exchange_gives_the_step_of_the_single_exchange_over_gloo():
+    """Two ranks: the flat state cut into buckets (each sharded over the ranks by itself, some reduced early)
+    against the one-bucket layout.  Without clipping the updated weights agree bit for bit (every element sees
+    the same mean gradient and the same AdamW arithmetic); the gradient norm is a sum in another order, so with
+    clipping the weights agree to rounding."""
+    import pytest
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bucketed_rank, args=(r, 2, 29764, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out in res:
+        assert isinstance(out, dict), out
+        norms1, norms2, same, close = out[1e9]
+        assert norms2 == pytest.approx(norms1, rel=1e-6) and same
+        norms1, norms2, same, close = out[0.5]
+        assert norms2 == pytest.approx(norms1, rel=1e-6) and close
