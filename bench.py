@@ -262,7 +262,10 @@ def trainer_measure(dev, world: int, steps: int, warmup: int, cpu: bool, cpu_sec
         out["fsdp_blocks_per_group"] = fsdp_groups
     else:
         out["data_parallel"] = ("whole bf16 model and fp32 gradient sum per GPU, fp32 master weights and AdamW state "
-                                "sharded; one reduce-scatter and one all-gather per step")
+                                "sharded; per step one reduce-scatter and one all-gather per bucket, the "
+                                "reduce-scatters started from inside the last backward pass")
+        out["exchange"] = {"buckets": len(replica.state.buckets), "overlapped_with_backward": replica.overlap,
+                           "buckets_reduced_inside_backward": replica.bucket_launches}
         out["micro_batches"] = {"replayed_from_hip_graphs": replica.replays, "run_eagerly": replica.eager_runs}
         if replica.capture_errors:
             out["capture_errors"] = list(replica.capture_errors.values())
