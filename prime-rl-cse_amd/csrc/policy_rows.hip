@@ -22,6 +22,8 @@
 // (unusual) case that the caller's backward arrives with another value.
 // Sequence mode needs the whole sample's sum before any token's gradient is
 // known, and fp32 rows do not fit the registers: both take the two-kernel path.
+#include <type_traits>
+
 #include "logprob_dev.h"
 
 // Build-time tunables (defaults = measured best on MI355X; tools/tune_rows.py builds and compares variants)
@@ -33,6 +35,25 @@
 #endif
 #ifndef PRL_ROWS_XCD_BLOCKS
 #define PRL_ROWS_XCD_BLOCKS 1  // 1: each of the 8 XCDs works through one contiguous eighth of the rows
+#endif
+
+// Two other ways of going from one row to the next were built and measured against the default (a fresh workgroup
+// per row), T = 2048, V = 151936, every token with a gradient, interleaved random-order rounds in one process:
+//   fresh workgroup per row (default)                                    218.6 us
+//   PRL_ROWS_WALK=1: one workgroup per compute unit walks over its rows,
+//     the next row's loads issued right behind this row's last store     223.5 us
+//   PRL_ROWS_WALK=1 PRL_ROWS_INTERLEAVE=1: the same, the next row's chunk
+//     j asked for right behind the store of this row's chunk j (reads and
+//     writes mixed inside a compute unit, waits counted by hand)         240.4 us
+// Both pass the parity tests; neither is compiled unless its flag is set.  Walking saves the workgroup turnover but
+// deals the rows out statically; mixing reads into the write stream delays both: a wave's loads and stores retire
+// through one in-order counter, so the next row's first chunk is not usable before this row's stores are
+// acknowledged, and the sums pass, which a fresh workgroup runs under its own loads, then starts late.
+#ifndef PRL_ROWS_WALK
+#define PRL_ROWS_WALK 0
+#endif
+#ifndef PRL_ROWS_INTERLEAVE
+#define PRL_ROWS_INTERLEAVE 0  // needs PRL_ROWS_WALK=1
 #endif
 
 #ifndef PRL_ROWS_TRACE
@@ -306,6 +327,482 @@ __global__ __launch_bounds__(kRowThreads) void k_policy_rows(
   }
 }
 
+#if PRL_ROWS_WALK && !PRL_ROWS_INTERLEAVE
+// The same row arithmetic with the workgroups walking: a launch has one workgroup per compute unit (a row's
+// registers leave room for no second one), and each walks over its share of the rows.  What that buys: the
+// loads of the next row are issued right behind the last store of this row's gradient, so the memory system
+// goes from writing to reading without waiting for a workgroup to end and another to start.  The loads are
+// never interleaved with the stores (a row's gradient is written in one stretch, the next row is then read in
+// one stretch): the compute units run through the same phases at about the same time, and pure read and pure
+// write stretches stream faster than a mix.  Rows are dealt out statically: XCD x takes the x-th eighth of the
+// rows, its workgroups take every (workgroups per XCD)-th row of that eighth.
+template <int NCH>
+__global__ __launch_bounds__(kRowThreads) void k_policy_rows_walk(
+    const char* __restrict__ logits, int64_t T, int64_t V, int64_t in_stride_bytes, const int64_t* __restrict__ ids,
+    const float* __restrict__ old, const float* __restrict__ adv, const uint32_t* __restrict__ mask_words,
+    int mask_mis, int skip_masked, float inv_temp, float clip, float inv_scale, float* __restrict__ lp_out,
+    float* __restrict__ ent_out, float* __restrict__ lse_out, char* __restrict__ dlogits, int64_t out_stride_bytes) {
+  __shared__ float red_m[kRowWaves], red_s[kRowWaves], red_w[kRowWaves];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
+  // (the host checks T < 2^31: rows are counted in 32 bits, which keeps the loop's state in few scalar registers)
+  const int nrows = (int)T;
+  const int per_xcd = (int)(gridDim.x >> 3);                // gridDim.x is a multiple of 8
+  const int rows_per_xcd = (nrows + 7) >> 3;
+  const int xcd_first = (int)(blockIdx.x & 7) * rows_per_xcd;
+  int xcd_last = xcd_first + rows_per_xcd;                  // one past this XCD's last row
+  if (xcd_last > nrows) xcd_last = nrows;
+  int row = xcd_first + (int)(blockIdx.x >> 3);
+  if (row >= xcd_last) return;
+
+  const int nchunk = (int)(V >> 3);
+  const float c2 = inv_temp * kLog2e;
+  const uint32_t lane_off = (uint32_t)tid * 16u;
+  constexpr int kSlab = kRowThreads * 16;
+  constexpr int kRsrcFlags = 0x00020000;
+  const int row_bytes = (int)(V * 2);
+
+  // whether a row's logits are read at all: not the last row (it predicts nothing) and not a row whose token
+  // nobody looks at
+  auto row_is_read = [&](int r) -> bool {
+    if (r + 1 >= nrows) return false;
+    return !(skip_masked && uniform_byte(mask_words, mask_mis, r + 1) == 0);
+  };
+  u32x4 buf[NCH];
+  // The slab offsets j * kSlab go into a scalar register each.  Left alone, the compiler keeps all of them
+  // alive around the loop (19 registers for the loads, more for the stores) and spills; a zero it cannot see
+  // through makes it form each offset where it is used (one scalar add).
+  auto opaque_zero = []() -> int {
+    int z;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+    return z;
+  };
+  auto issue_loads = [&](int r) {
+    const auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(logits + (int64_t)r * in_stride_bytes),
+                                                           0, row_bytes, kRsrcFlags);
+    const int z = opaque_zero();
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      buf[j] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, lane_off, z + j * kSlab, PRL_ROWS_NT_LOAD ? 2 : 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  bool have = row_is_read(row);
+  if (have) issue_loads(row);
+  while (true) {
+    const int next = row + per_xcd;
+    const bool more = next < xcd_last;
+    const bool next_have = more && row_is_read(next);
+    const int t = row + 1;
+    const auto out_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(dlogits + (int64_t)row * out_stride_bytes, 0, row_bytes, kRsrcFlags);
+    // One path for every kind of row, so that the row's registers have one life around the loop: a row that is
+    // not read (or whose token turns out to have no gradient) goes through the gradient pass with gi = 0 and
+    // stores zeros; what that pass computes from whatever the registers hold is thrown away.
+    float gi = 0.0f, lse2 = 0.0f, x_label = 0.0f;
+    int64_t label = -1;
+    if (!have) {
+      if (tid == 0) {
+        if (t >= nrows) {  // the last row predicts nothing; its workgroup also emits token 0, which no row predicts
+          if (skip_masked && uniform_byte(mask_words, mask_mis, 0) == 0)
+            emit_skipped(0, lp_out, ent_out, lse_out);
+          else
+            emit_zero_row(V, 0, lp_out, ent_out, lse_out);
+        } else {
+          emit_skipped(t, lp_out, ent_out, lse_out);
+        }
+      }
+    } else {
+      const bool m = uniform_byte(mask_words, mask_mis, t) != 0;
+      label = ids[t];
+      x_label = __builtin_nanf("");
+      if (label >= 0 && label < V)
+        x_label = uniform_bf16(reinterpret_cast<const uint32_t*>(logits) + (int64_t)row * (in_stride_bytes >> 2), label);
+      const float old_t = old[t], adv_t = adv[t];
+      auto chunk = [&](int j, float& prev) -> u32x4 {
+        touch_after(buf[j], prev);
+        u32x4 v = buf[j];
+        if (j >= NCH - kTailSlabs) {
+          const bool in = tid < nchunk - j * kRowThreads;
+          v.x = in ? v.x : 0xff7fff7fu;
+          v.y = in ? v.y : 0xff7fff7fu;
+          v.z = in ? v.z : 0xff7fff7fu;
+          v.w = in ? v.w : 0xff7fff7fu;
+        }
+        return v;
+      };
+      auto sums = [&](float M, float& M_out, float& s_out, float& w_out) {
+        float es[4] = {0.0f, 0.0f, 0.0f, 0.0f}, ws[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+          float x[8];
+          decode16_raw<PRL_BF16>(chunk(j, ws[3]), x);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float e = fast_exp2(fmaf(x[i], c2, -M));
+            es[i & 3] += e;
+            ws[i & 3] = fmaf(x[i], e, ws[i & 3]);
+          }
+        }
+        const float s = wave_sum((es[0] + es[2]) + (es[1] + es[3]));
+        const float w = wave_sum((ws[0] + ws[2]) + (ws[1] + ws[3]));
+        if (lane == 0) {
+          red_m[wid] = M;
+          red_s[wid] = s;
+          red_w[wid] = w;
+        }
+        __syncthreads();
+        float Mx = red_m[0];
+#pragma unroll
+        for (int i = 1; i < kRowWaves; ++i) Mx = fmaxf(Mx, red_m[i]);
+        float st = 0.0f, wt = 0.0f;
+#pragma unroll
+        for (int i = 0; i < kRowWaves; ++i) {
+          const float sc = fast_exp2(red_m[i] - Mx);
+          st = fmaf(red_s[i], sc, st);
+          wt = fmaf(red_w[i], sc, wt);
+        }
+        M_out = Mx;
+        s_out = st;
+        w_out = wt;
+      };
+      float mx = kNegBig;
+      {
+        float x[8];
+        decode16_raw<PRL_BF16>(chunk(0, mx), x);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mx = fmaxf(mx, x[i]);
+      }
+      float M, s, w;
+      sums(wave_max(mx) * c2, M, s, w);
+      if (!(s <= 3.0e38f) || !(s > 0.0f) || fabsf(w) > 3.0e38f) {  // see k_policy_rows: exact two-pass soft-max
+        __syncthreads();
+        mx = kNegBig;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+          float x[8];
+          decode16_raw<PRL_BF16>(chunk(j, mx), x);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) mx = fmaxf(mx, x[i]);
+        }
+        mx = wave_max(mx);
+        if (lane == 0) red_m[wid] = mx;
+        __syncthreads();
+        mx = red_m[0];
+#pragma unroll
+        for (int i = 1; i < kRowWaves; ++i) mx = fmaxf(mx, red_m[i]);
+        __syncthreads();
+        sums(mx * c2, M, s, w);
+      }
+      __syncthreads();  // the next row's sums rewrite red_*: every wave has read this row's first
+      lse2 = M + fast_log2(s);
+      const float lse = lse2 * kLn2;
+      const float lp = x_label * inv_temp - lse;
+      if (tid == 0) {
+        if (lse_out) lse_out[t] = lse;
+        if (lp_out) lp_out[t] = lp;
+        if (ent_out) ent_out[t] = lse - (w / s) * inv_temp;
+      }
+      const float r = expf(lp - old_t);
+      const float through = (r <= clip) ? -(inv_scale * adv_t) : 0.0f;
+      const float g = m ? through * r : 0.0f;
+      gi = g * inv_temp;
+    }
+    {
+      const bool live = gi != 0.0f;  // (a NaN counts as a gradient, as in the reference)
+      const float shift2 = fast_log2(fabsf(gi)) - lse2;
+      const uint32_t sign2 = gi > 0.0f ? 0x80008000u : 0u;
+      const uint32_t keep = live ? 0xffffffffu : 0u;
+      const int z0 = opaque_zero();
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) {
+        touch(buf[j]);
+        float x[8], d[8];
+        decode16_raw<PRL_BF16>(buf[j], x);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d[i] = fast_exp2(fmaf(x[i], c2, shift2));
+        u32x4 v;
+        v.x = (pack_bf16(d[0], d[1]) | sign2) & keep;
+        v.y = (pack_bf16(d[2], d[3]) | sign2) & keep;
+        v.z = (pack_bf16(d[4], d[5]) | sign2) & keep;
+        v.w = (pack_bf16(d[6], d[7]) | sign2) & keep;
+        store_chunk(v, out_rsrc, lane_off, z0 + j * kSlab);
+      }
+      if (live && label >= 0 && label < V && tid == (int)((label >> 3) & (kRowThreads - 1))) {
+        const float p = fast_exp2(fmaf(x_label, c2, -lse2));
+        reinterpret_cast<uint16_t*>(dlogits + (int64_t)row * out_stride_bytes)[label] = one_bf16(fmaf(-gi, p, gi));
+      }
+    }
+    if (!more) break;
+    if (next_have) issue_loads(next);  // right behind this row's last store
+    row = next;
+    have = next_have;
+  }
+}
+
+#endif  // PRL_ROWS_WALK && !PRL_ROWS_INTERLEAVE
+
+#if PRL_ROWS_WALK && PRL_ROWS_INTERLEAVE
+// Walking workgroups with reads and writes mixed: while a row's gradient is written chunk by chunk, chunk j of
+// the workgroup's NEXT row is asked for into the registers chunk j has just left, so a compute unit has loads and
+// stores in flight together and starts summing the next row as soon as its gradient pass is over.
+//
+// The compiler's wait-count pass cannot describe this (it merges the prologue, where 19 loads are in flight, with
+// the loop, where 19 stores and 19 loads alternate, and waits for half of everything before the first chunk), so
+// the loads are issued from inline assembly, which it does not track, and every wait is written by hand.  Vector
+// memory operations of a wave retire through ONE in-order counter on this architecture: "at most N operations
+// outstanding" means everything but the youngest N has completed.  Behind the load of chunk j the wave issues
+// 18 - j loads (first row) or 2 * (18 - j) stores and loads (later rows); operations a wave may or may not issue
+// on top (the three per-token results, the label's element) only make a wait stricter.
+template <int NCH>
+__global__ __launch_bounds__(kRowThreads) void k_policy_rows_mix(
+    const char* __restrict__ logits, int64_t T, int64_t V, int64_t in_stride_bytes, const int64_t* __restrict__ ids,
+    const float* __restrict__ old, const float* __restrict__ adv, const uint32_t* __restrict__ mask_words,
+    int mask_mis, int skip_masked, float inv_temp, float clip, float inv_scale, float* __restrict__ lp_out,
+    float* __restrict__ ent_out, float* __restrict__ lse_out, char* __restrict__ dlogits, int64_t out_stride_bytes) {
+  __shared__ float red_m[kRowWaves], red_s[kRowWaves], red_w[kRowWaves];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
+  const int nrows = (int)T;
+  const int per_xcd = (int)(gridDim.x >> 3);
+  const int rows_per_xcd = (nrows + 7) >> 3;
+  const int xcd_first = (int)(blockIdx.x & 7) * rows_per_xcd;
+  int xcd_last = xcd_first + rows_per_xcd;
+  if (xcd_last > nrows) xcd_last = nrows;
+  int row = xcd_first + (int)(blockIdx.x >> 3);
+  if (row >= xcd_last) return;
+
+  const int nchunk = (int)(V >> 3);
+  const float c2 = inv_temp * kLog2e;
+  const uint32_t lane_off = (uint32_t)tid * 16u;
+  constexpr int kSlab = kRowThreads * 16;
+  constexpr int kRsrcFlags = 0x00020000;
+  const int row_bytes = (int)(V * 2);
+
+  auto row_is_read = [&](int r) -> bool {
+    if (r + 1 >= nrows) return false;
+    return !(skip_masked && uniform_byte(mask_words, mask_mis, r + 1) == 0);
+  };
+  auto opaque_zero = []() -> int {
+    int z;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+    return z;
+  };
+  // the row's buffer descriptor as four scalar words (what make_buffer_rsrc builds for the intrinsics)
+  auto descriptor = [&](const char* base) -> u32x4 {
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    u32x4 d;
+    d.x = (uint32_t)a;
+    d.y = (uint32_t)(a >> 32) & 0xffffu;
+    d.z = (uint32_t)row_bytes;
+    d.w = (uint32_t)kRsrcFlags;
+    return d;
+  };
+  u32x4 buf[NCH];
+  auto load_chunk = [&](int j, const u32x4& rsrc, int soffset) {
+    // (no "memory" clobber: with one the compiler has to assume that the logits change under it and reads the
+    // label's element with a vector load, whose wait drains every load in flight; the position among the stores
+    // is pinned by the scheduling barriers on both sides)
+    __builtin_amdgcn_sched_barrier(0);
+#if PRL_ROWS_NT_LOAD
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen nt" : "=v"(buf[j]) : "v"(lane_off), "s"(rsrc), "s"(soffset));
+#else
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(buf[j]) : "v"(lane_off), "s"(rsrc), "s"(soffset));
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  bool have = row_is_read(row);
+  int first_i = 1;  // 1: the row in the registers was asked for by the prologue (only loads behind each load)
+  if (have) {
+    const u32x4 rsrc = descriptor(logits + (int64_t)row * in_stride_bytes);
+    const int z = opaque_zero();
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) load_chunk(j, rsrc, z + j * kSlab);
+  }
+  while (true) {
+    // Values derived from the lane's index (tail predicates, the label's owner, ...) are cheap; left to itself the
+    // compiler computes them once in front of the loop and keeps every one of them in a register around it,
+    // which the row's 76 registers leave no room for.  An index it cannot see through is recomputed per row.
+    int tid_l = tid;
+    asm volatile("" : "+v"(tid_l));
+    int64_t V_l = V;
+    asm volatile("" : "+s"(V_l));
+    const int next = row + per_xcd;
+    const bool more = next < xcd_last;
+    const bool next_have = more && row_is_read(next);
+    const int t = row + 1;
+    const auto out_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(dlogits + (int64_t)row * out_stride_bytes, 0, row_bytes, kRsrcFlags);
+    float gi = 0.0f, lse2 = 0.0f, x_label = 0.0f;
+    int64_t label = -1;
+    if (!have) {
+      if (tid_l == 0) {
+        if (t >= nrows) {
+          if (skip_masked && uniform_byte(mask_words, mask_mis, 0) == 0)
+            emit_skipped(0, lp_out, ent_out, lse_out);
+          else
+            emit_zero_row(V_l, 0, lp_out, ent_out, lse_out);
+        } else {
+          emit_skipped(t, lp_out, ent_out, lse_out);
+        }
+      }
+    } else {
+      const bool m = uniform_byte(mask_words, mask_mis, t) != 0;
+      label = ids[t];
+      x_label = __builtin_nanf("");
+      if (label >= 0 && label < V) {
+        // the label's logit through the scalar cache, spelled out: the compiler no longer proves that the logits
+        // stay unchanged (their address goes into the assembly loads) and would use a vector load, whose wait
+        // drains every row load in flight
+        const uint32_t* word = reinterpret_cast<const uint32_t*>(logits) + (int64_t)row * (in_stride_bytes >> 2) + (label >> 1);
+        uint32_t pair;
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pair) : "s"(word));
+        x_label = (label & 1) ? bf16_hi(pair) : bf16_lo(pair);
+      }
+      const float old_t = old[t], adv_t = adv[t];
+      // Chunk j for arithmetic: waits until at most 18 - j (row asked for by the prologue: only loads behind
+      // each load) or 2 * (18 - j) (row asked for during a gradient pass: a store and a load alternate)
+      // operations of this wave are outstanding.  One copy of the code for both: a scalar branch around the wait.
+      auto chunk = [&](int j, float& prev) -> u32x4 {
+        asm volatile(
+            "s_cmp_eq_u32 %2, 0\n\t"
+            "s_cbranch_scc1 1f\n\t"
+            "s_waitcnt vmcnt(%3)\n\t"
+            "s_branch 2f\n"
+            "1:\n\t"
+            "s_waitcnt vmcnt(%4)\n"
+            "2:"
+            : "+v"(buf[j]), "+v"(prev)
+            : "s"(first_i), "n"(NCH - 1 - j), "n"(2 * (NCH - 1 - j))
+            : "scc");
+        u32x4 v = buf[j];
+        if (j >= NCH - kTailSlabs) {
+          const bool in = tid_l < nchunk - j * kRowThreads;
+          v.x = in ? v.x : 0xff7fff7fu;
+          v.y = in ? v.y : 0xff7fff7fu;
+          v.z = in ? v.z : 0xff7fff7fu;
+          v.w = in ? v.w : 0xff7fff7fu;
+        }
+        return v;
+      };
+      auto sums = [&](float M, float& M_out, float& s_out, float& w_out) {
+        float es[4] = {0.0f, 0.0f, 0.0f, 0.0f}, ws[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+          float x[8];
+          decode16_raw<PRL_BF16>(chunk(j, ws[3]), x);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float e = fast_exp2(fmaf(x[i], c2, -M));
+            es[i & 3] += e;
+            ws[i & 3] = fmaf(x[i], e, ws[i & 3]);
+          }
+        }
+        const float s = wave_sum((es[0] + es[2]) + (es[1] + es[3]));
+        const float w = wave_sum((ws[0] + ws[2]) + (ws[1] + ws[3]));
+        if (lane == 0) {
+          red_m[wid] = M;
+          red_s[wid] = s;
+          red_w[wid] = w;
+        }
+        __syncthreads();
+        float Mx = red_m[0];
+#pragma unroll
+        for (int i = 1; i < kRowWaves; ++i) Mx = fmaxf(Mx, red_m[i]);
+        float st = 0.0f, wt = 0.0f;
+#pragma unroll
+        for (int i = 0; i < kRowWaves; ++i) {
+          const float sc = fast_exp2(red_m[i] - Mx);
+          st = fmaf(red_s[i], sc, st);
+          wt = fmaf(red_w[i], sc, wt);
+        }
+        M_out = Mx;
+        s_out = st;
+        w_out = wt;
+      };
+      float mx = kNegBig;
+      float M, s, w;
+      {
+        float x[8];
+        decode16_raw<PRL_BF16>(chunk(0, mx), x);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mx = fmaxf(mx, x[i]);
+      }
+      sums(wave_max(mx) * c2, M, s, w);
+      if (!(s <= 3.0e38f) || !(s > 0.0f) || fabsf(w) > 3.0e38f) {  // see k_policy_rows: exact two-pass soft-max
+        __syncthreads();
+        mx = kNegBig;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+          float x[8];
+          decode16_raw<PRL_BF16>(chunk(j, mx), x);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) mx = fmaxf(mx, x[i]);
+        }
+        mx = wave_max(mx);
+        if (lane == 0) red_m[wid] = mx;
+        __syncthreads();
+        mx = red_m[0];
+#pragma unroll
+        for (int i = 1; i < kRowWaves; ++i) mx = fmaxf(mx, red_m[i]);
+        __syncthreads();
+        sums(mx * c2, M, s, w);  // (its waits are met already)
+      }
+      __syncthreads();  // the next row's sums rewrite red_*: every wave has read this row's first
+      lse2 = M + fast_log2(s);
+      const float lse = lse2 * kLn2;
+      const float lp = x_label * inv_temp - lse;
+      if (tid_l == 0) {
+        if (lse_out) lse_out[t] = lse;
+        if (lp_out) lp_out[t] = lp;
+        if (ent_out) ent_out[t] = lse - (w / s) * inv_temp;
+      }
+      const float r = expf(lp - old_t);
+      const float through = (r <= clip) ? -(inv_scale * adv_t) : 0.0f;
+      const float g = m ? through * r : 0.0f;
+      gi = g * inv_temp;
+    }
+    {
+      const bool live = gi != 0.0f;
+      const float shift2 = fast_log2(fabsf(gi)) - lse2;
+      const uint32_t sign2 = gi > 0.0f ? 0x80008000u : 0u;
+      const uint32_t keep = live ? 0xffffffffu : 0u;
+      const int z0 = opaque_zero();
+      const u32x4 next_rsrc = descriptor(logits + (int64_t)(next_have ? next : row) * in_stride_bytes);
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) {
+        touch(buf[j]);
+        float x[8], d[8];
+        decode16_raw<PRL_BF16>(buf[j], x);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d[i] = fast_exp2(fmaf(x[i], c2, shift2));
+        u32x4 v;
+        v.x = (pack_bf16(d[0], d[1]) | sign2) & keep;
+        v.y = (pack_bf16(d[2], d[3]) | sign2) & keep;
+        v.z = (pack_bf16(d[4], d[5]) | sign2) & keep;
+        v.w = (pack_bf16(d[6], d[7]) | sign2) & keep;
+        store_chunk(v, out_rsrc, lane_off, z0 + j * kSlab);
+        // chunk j of the next row into the registers chunk j of this row has just left (the uniform branch
+        // keeps the pattern "one store, one load" whenever there is a next row to read)
+        if (next_have)
+          load_chunk(j, next_rsrc, z0 + j * kSlab);
+        else
+          asm volatile("" : "=v"(buf[j]));  // (dead either way: one life per chunk for the register allocator)
+      }
+      if (live && label >= 0 && label < V && tid_l == (int)((label >> 3) & (kRowThreads - 1))) {
+        const float p = fast_exp2(fmaf(x_label, c2, -lse2));
+        reinterpret_cast<uint16_t*>(dlogits + (int64_t)row * out_stride_bytes)[label] = one_bf16(fmaf(-gi, p, gi));
+      }
+    }
+    if (!more) break;
+    row = next;
+    have = next_have;
+    first_i = 0;
+  }
+}
+
+#endif  // PRL_ROWS_WALK && PRL_ROWS_INTERLEAVE
+
 // x *= scale[0] over T rows of V elements, unless scale[0] is exactly 1 (then nothing is read or written)
 template <int DT>
 __global__ __launch_bounds__(256) void k_scale_rows_if_not_one(char* __restrict__ x, int64_t T, int64_t V,
@@ -330,6 +827,19 @@ __global__ __launch_bounds__(256) void k_scale_rows_if_not_one(char* __restrict_
 }
 
 static int chunks_needed(int64_t V) { return (int)(((V >> 3) + kRowThreads - 1) / kRowThreads); }
+
+// Compute units of the current device (asked once per device; 256 on MI355X).
+static int compute_units() {
+  static int cached[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) return -1;
+    cached[dev] = n;
+  }
+  return cached[dev];
+}
 
 }  // namespace prl
 
@@ -370,10 +880,30 @@ extern "C" int prl_policy_rows_fwd_bwd(const void* logits, int logits_dtype, int
   const int mask_mis = (int)(reinterpret_cast<uintptr_t>(mask) & 3);
   const uint32_t* mask_words = reinterpret_cast<const uint32_t*>(mask - mask_mis);
   hipStream_t st = (hipStream_t)stream;
+#if PRL_ROWS_WALK
+  int cus = compute_units();
+  if (cus <= 0) {
+    set_error("policy_rows_fwd_bwd: cannot read the device's number of compute units");
+    return PRL_ELAUNCH;
+  }
+  int64_t nwg = (T + 7) / 8 * 8;
+  if (nwg > cus / 8 * 8) nwg = cus / 8 * 8;  // one workgroup per compute unit, the same number on every XCD
+  const dim3 wgrid((unsigned)nwg);
+#if PRL_ROWS_INTERLEAVE
+#define PRL_WALK_KERNEL k_policy_rows_mix
+#else
+#define PRL_WALK_KERNEL k_policy_rows_walk
+#endif
+#define PRL_ROWS(N)                                                                                               \
+  hipLaunchKernelGGL((PRL_WALK_KERNEL<N>), wgrid, block, 0, st, (const char*)logits, T, V, row_stride * 2, ids, \
+                     old, adv, mask_words, mask_mis, skip_masked ? 1 : 0, inv_temp, clip_ratio, 1.0f / scale,     \
+                     logprob, entropy, lse, (char*)dlogits, out_row_stride * 2)
+#else
 #define PRL_ROWS(N)                                                                                                \
   hipLaunchKernelGGL((k_policy_rows<N>), grid, block, 0, st, (const char*)logits, T, V, row_stride * 2, ids, old, \
                      adv, mask_words, mask_mis, skip_masked ? 1 : 0, inv_temp, clip_ratio, 1.0f / scale, logprob, entropy, lse,   \
                      (char*)dlogits, out_row_stride * 2)
+#endif
   // sizes at most kTailSlabs = 4 apart, so that the row always ends in the last 4 slabs of its kernel
   if (need <= 2)
     PRL_ROWS(2);

@@ -22,6 +22,8 @@ VARIANTS = {
     "plain_store": {"PRL_ROWS_NT_STORE": 0},
     "plain_load": {"PRL_ROWS_NT_LOAD": 0},
     "rows_in_launch_order": {"PRL_ROWS_XCD_BLOCKS": 0},
+    "walking_workgroups": {"PRL_ROWS_WALK": 1},
+    "walking_reads_in_the_write_stream": {"PRL_ROWS_WALK": 1, "PRL_ROWS_INTERLEAVE": 1},
     "trace": {"PRL_ROWS_TRACE": 1},
 }
 
