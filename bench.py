@@ -45,6 +45,15 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 EXIT_TRAINER_EXTRA_HUNG = 3  # exit code when the whole-trainer-step extra (or the barrier behind it) never returned
 
 
+# recipe -> (TOML under tools/recipes, what it stands for)
+RECIPES = {
+    "reverse_text": ("reverse_text_fake.toml", "Qwen3-0.6B reverse_text GRPO, rows of 16 x 128 tokens"),
+    "wordle": ("wordle_1p7b_fake.toml", "Qwen3-1.7B wordle GRPO, rows of 1 x 4096 tokens, 32 rollouts per rank and step"),
+    "hendrycks_7b": ("hendrycks_7b_fake.toml", "Qwen2.5-7B hendrycks_math GRPO, rows of 2 x 2048 tokens, activation "
+                                               "checkpointing, 32 rollouts per rank and step"),
+}
+
+
 def parse(argv: list[str] | None = None) -> argparse.Namespace:
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -67,6 +76,12 @@ def parse(argv: list[str] | None = None) -> argparse.Namespace:
     p.add_argument("--trainer-limit", type=float, default=180.0,
                    help="with --gpus N > 1: seconds after which the line is printed without the whole-trainer-step "
                         "extra and the process ends")
+    p.add_argument("--recipe", choices=sorted(RECIPES), default="reverse_text",
+                   help="reverse_text: the headline (the hot path of the Qwen3-0.6B recipe from resident logits, plus "
+                        "its whole trainer step as an extra). wordle / hendrycks_7b: the whole trainer step of that "
+                        "recipe's row shape through the trainer entry point (tools/recipes/*.toml: synthetic "
+                        "rollouts, 32 rollouts per rank and step, weights published every step); the line then "
+                        "reports that step and names the recipe in config.workload")
     p.add_argument("--launch-check", action="store_true",
                    help="ranks only meet, all-reduce one number and rank 0 prints what it saw: a test of the launch "
                         "path that needs no GPU (with PRL_BENCH_BACKEND=gloo)")
@@ -276,6 +291,45 @@ def trainer_measure(dev, world: int, steps: int, warmup: int, cpu: bool, cpu_sec
     return out
 
 
+def recipe_measure(recipe: str, world: int, steps: int, warmup: int) -> dict:
+    """`steps` timed optimizer steps of another recipe's shape through the trainer entry point itself
+    (prime_rl_cse_amd.train, the loop of src/prime_rl/trainer/rl/train.py:55-466): random-init model of the
+    recipe's architecture, FakeDataLoader rollouts, weight publication every step as in a real run."""
+    import statistics
+    import tempfile
+
+    from prime_rl_cse_amd.settings import RLTrainerConfig, parse_argv
+    from prime_rl_cse_amd.train import train
+
+    toml, what = RECIPES[recipe]
+    base = parse_argv(RLTrainerConfig, ["@", str(REPO / "tools" / "recipes" / toml)], use_env=False)
+    per_rank = base.data.fake.batch_size
+    with tempfile.TemporaryDirectory(prefix="prl_bench_") as out:
+        cfg = parse_argv(RLTrainerConfig, ["@", str(REPO / "tools" / "recipes" / toml), "--max-steps",
+                                           str(steps + warmup), "--output-dir", out, "--data.fake.batch-size",
+                                           str(per_rank * world)], use_env=False)
+        import contextlib
+
+        with contextlib.redirect_stdout(sys.stderr):  # the entry point logs every step; stdout is for the one line
+            history = train(cfg)  # starts and ends its own process group
+    rows = history[warmup:]
+    step_s = [r["time/step"] for r in rows]
+    fb_s = [r["time/forward_backward"] for r in rows]
+    sec = statistics.fmean(step_s)
+    tokens = per_rank * world * cfg.data.fake.seq_len
+    return {
+        "recipe": recipe, "what": what, "model": cfg.model.name, "samples_per_s": per_rank * world / sec,
+        "ms_per_step": 1e3 * sec, "ms_each_step": [round(1e3 * x, 1) for x in step_s],
+        "ms_forward_backward": 1e3 * statistics.fmean(fb_s), "tokens_per_s": tokens / sec,
+        "mfu_percent": statistics.fmean(r["perf/mfu"] for r in rows),
+        "peak_memory_gib": max(r["perf/peak_memory"] for r in rows),
+        "rollouts_per_rank_and_step": per_rank, "micro_batch_size": cfg.data.fake.micro_batch_size,
+        "seq_len": cfg.data.fake.seq_len, "loss": rows[-1].get("loss/mean"), "grad_norm": rows[-1]["optim/grad_norm"],
+        "timing": "mean of the entry point's own time/step over the timed steps (each ends with the host reading "
+                  "the step's statistics, so it spans the step's GPU work); the first steps are left out as warm-up",
+    }
+
+
 def trainer_cpu_baseline(batch, seconds: float) -> dict:
     """The same step on the host cores: fp32 model on the CPU, the oracle's loss, AdamW; a bounded sample of
     micro-batches (the reference trainer itself refuses to run without CUDA)."""
@@ -414,6 +468,21 @@ def main(argv: list[str] | None = None) -> int:
     backend = os.environ.get("PRL_BENCH_BACKEND", "nccl")
     if args.launch_check:
         launch_check(rank, world, backend, local)
+        return 0
+    if args.recipe != "reverse_text":
+        for k, v in dict(MASTER_ADDR="127.0.0.1", MASTER_PORT="29579", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                         LOCAL_WORLD_SIZE="1").items():
+            os.environ.setdefault(k, v)
+        info = recipe_measure(args.recipe, world, args.steps, max(args.warmup, 2))
+        if rank == 0:
+            print(json.dumps({
+                "metric": "policy_update_samples_per_sec", "value": info["samples_per_s"], "unit": "samples/s",
+                "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 2), "ms_per_step": info["ms_per_step"],
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": f"whole trainer step through the entry point, recipe {args.recipe}: {info['what']}",
+                           "global_batch": world * info["rollouts_per_rank_and_step"], "seq_len": info["seq_len"],
+                           "micro_batch": info["micro_batch_size"], "parallelism": f"dp{world}"},
+                "trainer_step": info}), flush=True)
         return 0
     local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
