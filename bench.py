@@ -51,6 +51,9 @@ RECIPES = {
     "wordle": ("wordle_1p7b_fake.toml", "Qwen3-1.7B wordle GRPO, rows of 1 x 4096 tokens, 32 rollouts per rank and step"),
     "hendrycks_7b": ("hendrycks_7b_fake.toml", "Qwen2.5-7B hendrycks_math GRPO, rows of 2 x 2048 tokens, activation "
                                                "checkpointing, 32 rollouts per rank and step"),
+    "hendrycks_32b_8_layers": ("hendrycks_32b_8_layers_fake.toml",
+                               "Qwen2.5-32B hendrycks_math GRPO cut to 8 of its 64 blocks (what one GPU holds), rows of "
+                               "8 x 2048 tokens, activation checkpointing, 32 rollouts per rank and step"),
 }
 
 
@@ -78,7 +81,7 @@ def parse(argv: list[str] | None = None) -> argparse.Namespace:
                         "extra and the process ends")
     p.add_argument("--recipe", choices=sorted(RECIPES), default="reverse_text",
                    help="reverse_text: the headline (the hot path of the Qwen3-0.6B recipe from resident logits, plus "
-                        "its whole trainer step as an extra). wordle / hendrycks_7b: the whole trainer step of that "
+                        "its whole trainer step as an extra). wordle / hendrycks_7b / hendrycks_32b_8_layers: the whole trainer step of that "
                         "recipe's row shape through the trainer entry point (tools/recipes/*.toml: synthetic "
                         "rollouts, 32 rollouts per rank and step, weights published every step); the line then "
                         "reports that step and names the recipe in config.workload")
