@@ -127,6 +127,17 @@ int prl_logprob_bwd(const void* logits, int logits_dtype, int64_t T, int64_t V, 
                     int shift, void* dlogits, int out_dtype, int64_t out_row_stride, void* stream);
 
 /*
+ * prl_logprob_bwd over a selection of rows: row r is written only where row_select[r] != 0 (uint8 [T], device),
+ * every other row of dlogits keeps what it holds.  The second pass behind prl_policy_rows_seq_fwd_bwd, for the
+ * rows that call has marked as not written (one workgroup per row and piece, which leaves at once where the
+ * mark is 0).
+ */
+int prl_logprob_bwd_selected(const void* logits, int logits_dtype, int64_t T, int64_t V, int64_t row_stride,
+                             const int64_t* ids, const float* lse, const float* g, const float* gscale,
+                             float temperature, int shift, void* dlogits, int out_dtype, int64_t out_row_stride,
+                             const uint8_t* row_select, void* stream);
+
+/*
  * Sample boundaries of a packed row from its position ids.  Replaces
  * get_response_lengths (src/prime_rl/trainer/utils.py:36-69) bit for bit:
  * index i >= 1 opens a new sample iff pos[i] == 0, pos[i-1] != 0, i+1 < T and
@@ -223,6 +234,34 @@ int prl_policy_rows_fwd_bwd(const void* logits, int logits_dtype, int64_t T, int
                             int skip_masked, float temperature, float clip_ratio, float loss_scale, float* logprob,
                             float* entropy, float* lse, void* dlogits, int out_dtype, int64_t out_row_stride,
                             void* stream);
+
+/*
+ * Sequence-mode forward AND backward of one packed row in a single pass over the logits (ratio_type "sequence":
+ * one importance ratio per sample, src/prime_rl/trainer/rl/loss.py:92-96, 107-108; the chain replaced is the same
+ * src/prime_rl/trainer/rl/train.py:285-310 as for prl_policy_rows_fwd_bwd).  A token's gradient needs the summed
+ * log-ratio of its whole sample.  The workgroups of a sample run at the same time (they start in row order, one
+ * per compute unit); each publishes its token's masked log-ratio to device memory and waits, for a bounded time,
+ * until its sample's other tokens are there; then
+ *   dlogits[t-1, :] = g_s / temperature * (onehot(ids[t]) - softmax(logits[t-1] / temperature))   for mask[t],
+ * with g_s the sample's dloss/dlogprob as prl_grpo_loss defines it (incoming gradient 1), zero rows elsewhere.
+ * logprob, entropy, lse as prl_logprob_entropy_fwd with shift = 1 (skip_masked as in prl_policy_forward).
+ *
+ * pending (uint8 [T], device, written for every row): 1 where the row's gradient has NOT been written, because its
+ * sample is longer than max_wait_len tokens (at most about 250 can be resident together) or because its
+ * workgroup gave up waiting after spin_limit sweeps.  The caller finishes with
+ *   prl_policy_tail (loss, logged tensors, g)  and  prl_logprob_bwd_selected(..., g, ..., row_select = pending).
+ * Results do not depend on which rows ended up pending beyond rounding (the second pass computes the same
+ * gradient from the same g).  workspace: prl_policy_rows_seq_workspace_bytes(T) bytes, 16-byte aligned; the call
+ * clears what it needs of it.  Same limits as prl_policy_rows_fwd_bwd (prl_policy_rows_supported).
+ */
+size_t prl_policy_rows_seq_workspace_bytes(int64_t T);
+int prl_policy_rows_seq_fwd_bwd(const void* logits, int logits_dtype, int64_t T, int64_t V, int64_t row_stride,
+                                const int64_t* ids, const int64_t* pos, const float* adv, const float* old,
+                                const uint8_t* mask, int skip_masked, float temperature, int length_norm,
+                                float clip_ratio, float loss_scale, float* logprob, float* entropy, float* lse,
+                                void* dlogits, int out_dtype, int64_t out_row_stride, uint8_t* pending,
+                                int max_wait_len, int spin_limit, void* workspace, size_t workspace_bytes,
+                                void* stream);
 
 /*
  * x[T, V] *= scale[0] in place, where scale is a device scalar; when it is

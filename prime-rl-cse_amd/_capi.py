@@ -49,6 +49,18 @@ SIGNATURES = {
         [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,
          c_void_p, c_int, c_int64, c_void_p],
     ),
+    "prl_logprob_bwd_selected": (
+        c_int,
+        [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,
+         c_void_p, c_int, c_int64, c_void_p, c_void_p],
+    ),
+    "prl_policy_rows_seq_workspace_bytes": (c_size_t, [c_int64]),
+    "prl_policy_rows_seq_fwd_bwd": (
+        c_int,
+        [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
+         c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int, c_int,
+         c_void_p, c_size_t, c_void_p],
+    ),
     "prl_segments_from_position_ids": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "prl_grpo_loss": (
         c_int,

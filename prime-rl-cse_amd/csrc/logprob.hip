@@ -157,7 +157,7 @@ __global__ __launch_bounds__(NT) void k_logprob_bwd(const char* __restrict__ log
                                                     const float* __restrict__ lse, const float* __restrict__ g,
                                                     const float* __restrict__ gscale, float inv_temp, int shift,
                                                     char* __restrict__ out, int64_t out_stride_bytes, int nsplit,
-                                                    int64_t chunk) {
+                                                    int64_t chunk, const uint8_t* __restrict__ row_select) {
   constexpr int ESI = DTI == PRL_F32 ? 4 : 2;
   constexpr int ESO = DTO == PRL_F32 ? 4 : 2;
   constexpr int U = (DTI == PRL_BF16 || DTO == PRL_BF16) ? 8 : 4;  // elements per work unit
@@ -168,6 +168,7 @@ __global__ __launch_bounds__(NT) void k_logprob_bwd(const char* __restrict__ log
 #else
   const int64_t row = blockIdx.x / nsplit;
 #endif
+  if (row_select && row_select[row] == 0) return;  // a row somebody else has written already: left as it is
   const int k = (int)(blockIdx.x % nsplit);
   const int64_t e0 = k * chunk;
   int64_t n = V - e0;
@@ -397,10 +398,38 @@ int prl::logprob_fwd_impl(const void* logits, int logits_dtype, int64_t T, int64
   return PRL_OK;
 }
 
+static int logprob_bwd_impl(const void* logits, int logits_dtype, int64_t T, int64_t V, int64_t row_stride,
+                            const int64_t* ids, const float* lse, const float* g, const float* gscale,
+                            float temperature, int shift, void* dlogits, int out_dtype, int64_t out_row_stride,
+                            const uint8_t* row_select, void* stream);
+
 extern "C" int prl_logprob_bwd(const void* logits, int logits_dtype, int64_t T, int64_t V, int64_t row_stride,
                                const int64_t* ids, const float* lse, const float* g, const float* gscale,
                                float temperature, int shift, void* dlogits, int out_dtype, int64_t out_row_stride,
                                void* stream) {
+  return logprob_bwd_impl(logits, logits_dtype, T, V, row_stride, ids, lse, g, gscale, temperature, shift, dlogits,
+                          out_dtype, out_row_stride, nullptr, stream);
+}
+
+// Only the rows r with row_select[r] != 0 are written; the others keep what they hold.
+extern "C" int prl_logprob_bwd_selected(const void* logits, int logits_dtype, int64_t T, int64_t V,
+                                        int64_t row_stride, const int64_t* ids, const float* lse, const float* g,
+                                        const float* gscale, float temperature, int shift, void* dlogits,
+                                        int out_dtype, int64_t out_row_stride, const uint8_t* row_select,
+                                        void* stream) {
+  if (!row_select) {
+    clear_error();
+    set_error("logprob_bwd_selected: row_select must not be NULL");
+    return PRL_EINVAL;
+  }
+  return logprob_bwd_impl(logits, logits_dtype, T, V, row_stride, ids, lse, g, gscale, temperature, shift, dlogits,
+                          out_dtype, out_row_stride, row_select, stream);
+}
+
+static int logprob_bwd_impl(const void* logits, int logits_dtype, int64_t T, int64_t V, int64_t row_stride,
+                            const int64_t* ids, const float* lse, const float* g, const float* gscale,
+                            float temperature, int shift, void* dlogits, int out_dtype, int64_t out_row_stride,
+                            const uint8_t* row_select, void* stream) {
   clear_error();
   PRL_REQUIRE(T >= 0 && V >= 1, "logprob_bwd: need T >= 0 and V >= 1 (got T=%lld V=%lld)", (long long)T,
               (long long)V);
@@ -429,7 +458,8 @@ extern "C" int prl_logprob_bwd(const void* logits, int logits_dtype, int64_t T, 
     const int unit = (esi == 2 || eso == 2) ? 8 : 4;
     const bool flat_ok = V % unit == 0 && ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits) |
                                             (uintptr_t)sbi | (uintptr_t)sbo) & 15) == 0;
-    if (flat_ok) {
+    // (with a selection of rows: one workgroup per row, which looks at its row's mark and leaves at once)
+    if (flat_ok && !row_select) {
       constexpr int UPT = PRL_BWD_FLAT_UPT;
       const int64_t per_piece = (int64_t)kBwdThreads * UPT;
       const int64_t ppr = (V / unit + per_piece - 1) / per_piece;
@@ -456,7 +486,7 @@ extern "C" int prl_logprob_bwd(const void* logits, int logits_dtype, int64_t T, 
   const dim3 grid((unsigned)(T * ns)), block(kBwdThreads);
 #define PRL_BWD(DI, DO)                                                                                             \
   hipLaunchKernelGGL((k_logprob_bwd<DI, DO, kBwdThreads>), grid, block, 0, st, lg, T, V, sbi, ids, lse, g, gscale, \
-                     inv_temp, shift, out, sbo, ns, chunk)
+                     inv_temp, shift, out, sbo, ns, chunk, row_select)
   if (logits_dtype == PRL_F32 && out_dtype == PRL_F32)
     PRL_BWD(PRL_F32, PRL_F32);
   else if (logits_dtype == PRL_F32)

@@ -803,6 +803,274 @@ __global__ __launch_bounds__(kRowThreads) void k_policy_rows_mix(
 
 #endif  // PRL_ROWS_WALK && PRL_ROWS_INTERLEAVE
 
+// ---------------------------------------------------------------- sequence mode in one pass
+//
+// With one ratio per sample (src/prime_rl/trainer/rl/loss.py:92-96, 107-108) a token's gradient needs the summed
+// log-ratio of its whole sample, i.e. the log-probabilities of up to a few hundred other rows.  Those rows are being
+// worked on at the same time: workgroups start in the order of their index, one per compute unit, so the
+// workgroups of a sample of up to ~250 tokens are all resident together.  Each publishes its token's masked
+// log-ratio as an 8-byte {tag, value} word (a write-through store at device scope, the data is its own flag),
+// then one wave re-reads the words of the workgroup's sample until all carry the tag, sums them in a fixed order
+// and the row's gradient is written from the registers as in token mode: the logits are read once.
+//
+// Nothing here relies on the start order for CORRECTNESS: the wait is bounded (`spin_limit` sweeps), and a workgroup
+// that gives up, or whose sample is longer than `max_wait_len`, writes no gradient and marks its row in `pending`;
+// the caller then runs prl_logprob_bwd_selected over the marked rows (a second read of those rows only).  A
+// workgroup publishes before it waits and waits for nothing but published words, so every workgroup ends.
+__device__ __forceinline__ void publish_log_ratio(unsigned long long* slots, int64_t t, float lr) {
+  __hip_atomic_store(slots + t, (1ull << 32) | (unsigned long long)__float_as_uint(lr), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int NCH>
+__global__ __launch_bounds__(kRowThreads) void k_policy_rows_seq(
+    const char* __restrict__ logits, int64_t T, int64_t V, int64_t in_stride_bytes, const int64_t* __restrict__ ids,
+    const float* __restrict__ old, const float* __restrict__ adv, const uint8_t* __restrict__ mask,
+    const uint32_t* __restrict__ mask_words, int mask_mis, int skip_masked,
+    float inv_temp, float clip, float inv_scale, int length_norm, const int32_t* __restrict__ seg_id,
+    const int64_t* __restrict__ seg_start, unsigned long long* slots, uint8_t* __restrict__ pending,
+    int max_wait_len, int spin_limit, float* __restrict__ lp_out, float* __restrict__ ent_out,
+    float* __restrict__ lse_out, char* __restrict__ dlogits, int64_t out_stride_bytes) {
+  __shared__ float red_m[kRowWaves], red_s[kRowWaves], red_w[kRowWaves];
+  __shared__ float sample_sums[4];  // ok, sum of log-ratios, sum of advantages, count (all over unmasked tokens)
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
+  const int64_t row = blockIdx.x;  // launch order IS row order here: a sample's rows start together
+  if (row >= T) return;
+  const int64_t t = row + 1;
+  const int nchunk = (int)(V >> 3);
+  const float c2 = inv_temp * kLog2e;
+  const uint32_t lane_off = (uint32_t)tid * 16u;
+  constexpr int kSlab = kRowThreads * 16;
+  constexpr int kRsrcFlags = 0x00020000;
+  const int row_bytes = (int)(V * 2);
+  const auto out_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(dlogits + row * out_stride_bytes, 0, row_bytes, kRsrcFlags);
+  auto zero_row = [&]() {
+    const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) store_chunk(z, out_rsrc, lane_off, j * kSlab);
+  };
+
+  // token 0, which no row predicts (it is scored against all-zero logits), belongs to the first sample: the first
+  // workgroup emits and publishes it, so that nobody waits for the last
+  if (row == 0 && tid == 0) {
+    const bool m0 = uniform_byte(mask_words, mask_mis, 0) != 0;
+    float lr0 = 0.0f;
+    if (skip_masked && !m0) {
+      emit_skipped(0, lp_out, ent_out, lse_out);
+    } else {
+      emit_zero_row(V, 0, lp_out, ent_out, lse_out);
+      const float lp0 = 0.0f - logf((float)V);
+      lr0 = m0 ? lp0 - old[0] : 0.0f;
+    }
+    publish_log_ratio(slots, 0, lr0);
+  }
+  if (t >= T) {  // the last row predicts nothing
+    zero_row();
+    if (tid == 0) pending[row] = 0;
+    return;
+  }
+  const bool m = uniform_byte(mask_words, mask_mis, t) != 0;  // (a scalar read: nothing the row's loads queue behind)
+  if (skip_masked && !m) {  // a token nobody looks at: no read, outputs 0, log-ratio 0, gradient 0
+    if (tid == 0) {
+      emit_skipped(t, lp_out, ent_out, lse_out);
+      publish_log_ratio(slots, t, 0.0f);
+      pending[row] = 0;
+    }
+    zero_row();
+    return;
+  }
+
+  const auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(logits + row * in_stride_bytes), 0,
+                                                         row_bytes, kRsrcFlags);
+  u32x4 buf[NCH];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    buf[j] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, lane_off, j * kSlab, PRL_ROWS_NT_LOAD ? 2 : 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const int64_t label = ids[t];
+  float x_label = __builtin_nanf("");
+  if (label >= 0 && label < V)
+    x_label = uniform_bf16(reinterpret_cast<const uint32_t*>(logits) + row * (in_stride_bytes >> 2), label);
+  const float old_t = old[t];
+  // the token's sample (the table was made by the launch before this one)
+  const int64_t sample = seg_id[t];
+  const int64_t first = seg_start[sample], last = seg_start[sample + 1];
+
+  auto chunk = [&](int j, float& prev) -> u32x4 {
+    touch_after(buf[j], prev);
+    u32x4 v = buf[j];
+    if (j >= NCH - kTailSlabs) {
+      const bool in = tid < nchunk - j * kRowThreads;
+      v.x = in ? v.x : 0xff7fff7fu;
+      v.y = in ? v.y : 0xff7fff7fu;
+      v.z = in ? v.z : 0xff7fff7fu;
+      v.w = in ? v.w : 0xff7fff7fu;
+    }
+    return v;
+  };
+  auto sums = [&](float M, float& M_out, float& s_out, float& w_out) {
+    float es[4] = {0.0f, 0.0f, 0.0f, 0.0f}, ws[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      float x[8];
+      decode16_raw<PRL_BF16>(chunk(j, ws[3]), x);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float e = fast_exp2(fmaf(x[i], c2, -M));
+        es[i & 3] += e;
+        ws[i & 3] = fmaf(x[i], e, ws[i & 3]);
+      }
+    }
+    const float s = wave_sum((es[0] + es[2]) + (es[1] + es[3]));
+    const float w = wave_sum((ws[0] + ws[2]) + (ws[1] + ws[3]));
+    if (lane == 0) {
+      red_m[wid] = M;
+      red_s[wid] = s;
+      red_w[wid] = w;
+    }
+    __syncthreads();
+    float Mx = red_m[0];
+#pragma unroll
+    for (int i = 1; i < kRowWaves; ++i) Mx = fmaxf(Mx, red_m[i]);
+    float st = 0.0f, wt = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kRowWaves; ++i) {
+      const float sc = fast_exp2(red_m[i] - Mx);
+      st = fmaf(red_s[i], sc, st);
+      wt = fmaf(red_w[i], sc, wt);
+    }
+    M_out = Mx;
+    s_out = st;
+    w_out = wt;
+  };
+  float mx = kNegBig;
+  {
+    float x[8];
+    decode16_raw<PRL_BF16>(chunk(0, mx), x);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mx = fmaxf(mx, x[i]);
+  }
+  float M, s, w;
+  sums(wave_max(mx) * c2, M, s, w);
+  if (!(s <= 3.0e38f) || !(s > 0.0f) || fabsf(w) > 3.0e38f) {  // see k_policy_rows: exact two-pass soft-max
+    __syncthreads();
+    mx = kNegBig;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      float x[8];
+      decode16_raw<PRL_BF16>(chunk(j, mx), x);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) mx = fmaxf(mx, x[i]);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red_m[wid] = mx;
+    __syncthreads();
+    mx = red_m[0];
+#pragma unroll
+    for (int i = 1; i < kRowWaves; ++i) mx = fmaxf(mx, red_m[i]);
+    __syncthreads();
+    sums(mx * c2, M, s, w);
+  }
+  const float lse2 = M + fast_log2(s);
+  const float lse = lse2 * kLn2;
+  const float lp = x_label * inv_temp - lse;
+  if (tid == 0) {
+    if (lse_out) lse_out[t] = lse;
+    if (lp_out) lp_out[t] = lp;
+    if (ent_out) ent_out[t] = lse - (w / s) * inv_temp;
+    publish_log_ratio(slots, t, m ? lp - old_t : 0.0f);  // before any waiting
+  }
+  if (!m) {  // scored for the statistics, but masked out of the loss: no gradient whatever the sample's ratio is
+    zero_row();
+    if (tid == 0) pending[row] = 0;
+    return;
+  }
+  if (last - first > (int64_t)max_wait_len) {  // too long to be resident together: the caller's second pass does it
+    if (tid == 0) pending[row] = 1;
+    return;
+  }
+
+  // the sample's sums, once every one of its tokens has been published: one wave sweeps the words, lane i over the
+  // tokens first + i, first + i + 64, ... (the order in which the loss kernel adds them up, so that the gradient
+  // factor used here is the one it reports)
+  if (wid == 0) {
+    bool ok = false;
+    float s_lr = 0.0f;
+    for (int spin = 0; spin <= spin_limit; ++spin) {
+      bool all = true;
+      s_lr = 0.0f;
+      for (int64_t i = first + lane; i < last; i += kWave) {
+        const unsigned long long x = __hip_atomic_load(slots + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        all = all && (x >> 32) == 1ull;
+        s_lr += __uint_as_float((uint32_t)x);
+      }
+      if (__all(all ? 1 : 0)) {
+        ok = true;
+        break;
+      }
+      if (spin >= 8) __builtin_amdgcn_s_sleep(16);  // the sample's rows end within microseconds of each other
+    }
+    float s_adv = 0.0f, s_cnt = 0.0f;
+    for (int64_t i = first + lane; i < last; i += kWave) {
+      if (mask[i] != 0) {
+        s_adv += adv[i];
+        s_cnt += 1.0f;
+      }
+    }
+    s_lr = wave_sum(s_lr);
+    s_adv = wave_sum(s_adv);
+    s_cnt = wave_sum(s_cnt);
+    if (lane == 0) {
+      sample_sums[0] = ok ? 1.0f : 0.0f;
+      sample_sums[1] = s_lr;
+      sample_sums[2] = s_adv;
+      sample_sums[3] = s_cnt;
+    }
+  }
+  __syncthreads();
+  if (sample_sums[0] == 0.0f) {  // gave up waiting: the caller's second pass writes this row
+    if (tid == 0) pending[row] = 1;
+    return;
+  }
+  // dloss/dlogprob of an unmasked token of this sample (the expressions of the loss kernels, in their order)
+  const float cnt = fmaxf(sample_sums[3], 1.0f);
+  const float av = length_norm ? sample_sums[1] / cnt : sample_sums[1];
+  const float r = expf(av > 10.0f ? 10.0f : av);
+  const float g_c = -((inv_scale / cnt) * sample_sums[2]);
+  const float g_r = (r <= clip) ? g_c : 0.0f;
+  const float g_b = g_r * r;
+  const float g_a = (av <= 10.0f) ? g_b : 0.0f;
+  const float g = length_norm ? g_a / cnt : g_a;
+  const float gi = g * inv_temp;
+  if (tid == 0) pending[row] = 0;
+  if (gi == 0.0f) {
+    zero_row();
+    return;
+  }
+  const float shift2 = fast_log2(fabsf(gi)) - lse2;
+  const uint32_t sign2 = gi > 0.0f ? 0x80008000u : 0u;
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    touch(buf[j]);
+    float x[8], d[8];
+    decode16_raw<PRL_BF16>(buf[j], x);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d[i] = fast_exp2(fmaf(x[i], c2, shift2));
+    u32x4 v;
+    v.x = pack_bf16(d[0], d[1]) | sign2;
+    v.y = pack_bf16(d[2], d[3]) | sign2;
+    v.z = pack_bf16(d[4], d[5]) | sign2;
+    v.w = pack_bf16(d[6], d[7]) | sign2;
+    store_chunk(v, out_rsrc, lane_off, j * kSlab);
+  }
+  if (label >= 0 && label < V && tid == (int)((label >> 3) & (kRowThreads - 1))) {
+    const float p = fast_exp2(fmaf(x_label, c2, -lse2));
+    reinterpret_cast<uint16_t*>(dlogits + row * out_stride_bytes)[label] = one_bf16(fmaf(-gi, p, gi));
+  }
+}
+
 // x *= scale[0] over T rows of V elements, unless scale[0] is exactly 1 (then nothing is read or written)
 template <int DT>
 __global__ __launch_bounds__(256) void k_scale_rows_if_not_one(char* __restrict__ x, int64_t T, int64_t V,
@@ -842,6 +1110,11 @@ static int compute_units() {
 }
 
 }  // namespace prl
+
+namespace prl {
+int segments_impl(const int64_t* pos, int64_t T, int32_t* seg_id, int64_t* seg_start, int32_t* n_seg,
+                  unsigned long long* clear, int64_t n_clear, void* stream);
+}
 
 using namespace prl;
 
@@ -941,5 +1214,74 @@ extern "C" int prl_scale_rows_if_not_one(void* x, int dtype, int64_t T, int64_t 
     hipLaunchKernelGGL((k_scale_rows_if_not_one<PRL_BF16>), grid, block, 0, (hipStream_t)stream, (char*)x, T, V,
                        row_stride * es, scale);
   PRL_CHECK_LAUNCH("scale_rows_if_not_one");
+  return PRL_OK;
+}
+
+// Workspace of prl_policy_rows_seq_fwd_bwd: the published words (8 bytes per token), the sample of every token
+// (4 bytes), the samples' start offsets (8 bytes per token + 8) and their number.
+static size_t seq_ws_slots(int64_t T) { return (size_t)T * 8; }
+static size_t seq_ws_seg_start(int64_t T) { return seq_ws_slots(T) + (((size_t)T * 4 + 15) & ~(size_t)15); }
+static size_t seq_ws_n_seg(int64_t T) { return seq_ws_seg_start(T) + ((size_t)T + 1) * 8; }
+
+extern "C" size_t prl_policy_rows_seq_workspace_bytes(int64_t T) { return T > 0 ? seq_ws_n_seg(T) + 16 : 0; }
+
+extern "C" int prl_policy_rows_seq_fwd_bwd(const void* logits, int logits_dtype, int64_t T, int64_t V,
+                                           int64_t row_stride, const int64_t* ids, const int64_t* pos,
+                                           const float* adv, const float* old, const uint8_t* mask, int skip_masked,
+                                           float temperature, int length_norm, float clip_ratio, float loss_scale,
+                                           float* logprob, float* entropy, float* lse, void* dlogits, int out_dtype,
+                                           int64_t out_row_stride, uint8_t* pending, int max_wait_len, int spin_limit,
+                                           void* workspace, size_t workspace_bytes, void* stream) {
+  clear_error();
+  PRL_REQUIRE(prl_policy_rows_supported(logits_dtype, T, V, row_stride, out_dtype, out_row_stride),
+              "policy_rows_seq_fwd_bwd: shape or dtype not supported; ask prl_policy_rows_supported first");
+  PRL_REQUIRE(logits && ids && pos && adv && old && mask && logprob && lse && dlogits && pending && workspace,
+              "policy_rows_seq_fwd_bwd: logits, ids, pos, adv, old, mask, logprob, lse (the second pass reads it), "
+              "dlogits, pending and workspace must not be NULL");
+  PRL_REQUIRE(((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits)) & 15) == 0,
+              "policy_rows_seq_fwd_bwd: logits and dlogits must be 16-byte aligned");
+  PRL_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0 &&
+                  workspace_bytes >= prl_policy_rows_seq_workspace_bytes(T),
+              "policy_rows_seq_fwd_bwd: workspace too small or not 16-byte aligned (need %zu bytes)",
+              prl_policy_rows_seq_workspace_bytes(T));
+  PRL_REQUIRE(temperature > 0.0f && temperature - temperature == 0.0f,
+              "policy_rows_seq_fwd_bwd: temperature must be finite and positive");
+  PRL_REQUIRE(max_wait_len >= 0 && spin_limit >= 0 && spin_limit <= (1 << 20),
+              "policy_rows_seq_fwd_bwd: max_wait_len must be >= 0 and spin_limit in [0, 2^20]");
+  char* ws = (char*)workspace;
+  unsigned long long* slots = (unsigned long long*)ws;
+  int32_t* seg_id = (int32_t*)(ws + seq_ws_slots(T));
+  int64_t* seg_start = (int64_t*)(ws + seq_ws_seg_start(T));
+  int32_t* n_seg = (int32_t*)(ws + seq_ws_n_seg(T));
+  // the samples' table, and in the same launch the hand-off words back to "not published"
+  int rc = segments_impl(pos, T, seg_id, seg_start, n_seg, slots, T, stream);
+  if (rc != PRL_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const float scale = loss_scale > 1.0f ? loss_scale : 1.0f;
+  const float inv_temp = 1.0f / temperature;
+  const int need = chunks_needed(V);
+  const dim3 grid((unsigned)T), block(kRowThreads);
+  const int mask_mis = (int)(reinterpret_cast<uintptr_t>(mask) & 3);
+  const uint32_t* mask_words = reinterpret_cast<const uint32_t*>(mask - mask_mis);
+#define PRL_ROWS_SEQ(N)                                                                                               \
+  hipLaunchKernelGGL((k_policy_rows_seq<N>), grid, block, 0, st, (const char*)logits, T, V, row_stride * 2, ids, old, \
+                     adv, mask, mask_words, mask_mis, skip_masked ? 1 : 0, inv_temp, clip_ratio, 1.0f / scale,         \
+                     length_norm ? 1 : 0, seg_id,                                                                      \
+                     seg_start, slots, pending, max_wait_len, spin_limit, logprob, entropy, lse, (char*)dlogits,      \
+                     out_row_stride * 2)
+  if (need <= 2)
+    PRL_ROWS_SEQ(2);
+  else if (need <= 4)
+    PRL_ROWS_SEQ(4);
+  else if (need <= 8)
+    PRL_ROWS_SEQ(8);
+  else if (need <= 12)
+    PRL_ROWS_SEQ(12);
+  else if (need <= 16)
+    PRL_ROWS_SEQ(16);
+  else
+    PRL_ROWS_SEQ(19);
+#undef PRL_ROWS_SEQ
+  PRL_CHECK_LAUNCH("policy_rows_seq_fwd_bwd");
   return PRL_OK;
 }

@@ -19,8 +19,11 @@ __device__ __forceinline__ bool opens_sample(const int64_t* __restrict__ pos, in
 __global__ __launch_bounds__(kSegThreads) void k_segments(const int64_t* __restrict__ pos, int64_t T,
                                                           int32_t* __restrict__ seg_id,
                                                           int64_t* __restrict__ seg_start,
-                                                          int32_t* __restrict__ n_seg) {
+                                                          int32_t* __restrict__ n_seg,
+                                                          unsigned long long* __restrict__ clear, int64_t n_clear) {
   constexpr int NW = kSegThreads / kWave;
+  // words a later launch on this stream wants zeroed (the hand-off words of the one-pass sequence kernel)
+  for (int64_t i = threadIdx.x; i < n_clear; i += kSegThreads) clear[i] = 0ull;
   __shared__ int wave_total[NW];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
   int carry = 0;  // boundaries in front of the current step
@@ -58,15 +61,25 @@ __global__ __launch_bounds__(kSegThreads) void k_segments(const int64_t* __restr
 
 using namespace prl;
 
+namespace prl {
+int segments_impl(const int64_t* pos, int64_t T, int32_t* seg_id, int64_t* seg_start, int32_t* n_seg,
+                  unsigned long long* clear, int64_t n_clear, void* stream);
+}
+
 extern "C" int prl_segments_from_position_ids(const int64_t* pos, int64_t T, int32_t* seg_id, int64_t* seg_start,
                                               int32_t* n_seg, void* stream) {
+  return segments_impl(pos, T, seg_id, seg_start, n_seg, nullptr, 0, stream);
+}
+
+int prl::segments_impl(const int64_t* pos, int64_t T, int32_t* seg_id, int64_t* seg_start, int32_t* n_seg,
+                       unsigned long long* clear, int64_t n_clear, void* stream) {
   clear_error();
   PRL_REQUIRE(T >= 0, "segments_from_position_ids: T must be >= 0");
   PRL_REQUIRE(seg_start && n_seg, "segments_from_position_ids: seg_start and n_seg must not be NULL");
   PRL_REQUIRE(T == 0 || pos, "segments_from_position_ids: pos must not be NULL");
   PRL_REQUIRE(T < ((int64_t)1 << 31) - 2, "segments_from_position_ids: T too large");
   hipLaunchKernelGGL(k_segments, dim3(1), dim3(kSegThreads), 0, (hipStream_t)stream, pos, T, seg_id, seg_start,
-                     n_seg);
+                     n_seg, clear, clear ? n_clear : (int64_t)0);
   PRL_CHECK_LAUNCH("segments_from_position_ids");
   return PRL_OK;
 }

@@ -333,6 +333,23 @@ def unit_gradient(device: torch.device | str) -> Tensor:
     return t
 
 
+# which rows of the last sequence-mode call were left to the second pass (uint8 [T] on the device): for tests and
+# for looking at how often waits run out
+_LAST_SEQ_PENDING: list[Tensor | None] = [None]
+
+
+def _seq_rows_limits() -> tuple[int, int] | None:
+    """(longest sample whose workgroups wait for each other, sweeps a workgroup waits) of the one-pass
+    sequence-mode kernel, or None when it is switched off (PRL_SEQ_ROWS=0).  PRL_SEQ_ROWS_MAX_LEN (224: a launch
+    has one workgroup per compute unit, 256 of them, resident at a time) and PRL_SEQ_ROWS_SPINS (4096 sweeps of
+    about a microsecond) override the defaults; rows the kernel leaves out go through the second-pass kernel."""
+    import os
+
+    if os.environ.get("PRL_SEQ_ROWS", "1") == "0":
+        return None
+    return int(os.environ.get("PRL_SEQ_ROWS_MAX_LEN", "224")), int(os.environ.get("PRL_SEQ_ROWS_SPINS", "4096"))
+
+
 def _rows_kernel_enabled() -> bool:
     """The register-resident single-pass kernel is used whenever it applies; PRL_FUSED_ROWS=0 switches it off
     (for A/B measurements against the two-kernel path)."""
@@ -377,7 +394,51 @@ class _PolicyLoss(torch.autograd.Function):
             and logits.data_ptr() % 16 == 0
             and bool(lib.prl_policy_rows_supported(code, t, v, logits.stride(1), code, v))
         )
-        if single_pass:
+        seq_limits = _seq_rows_limits() if per_seq else None
+        seq_pass = (
+            per_seq and seq_limits is not None and t > 0 and ctx.needs_input_grad[0] and _rows_kernel_enabled()
+            and logits.data_ptr() % 16 == 0
+            and bool(lib.prl_policy_rows_supported(code, t, v, logits.stride(1), code, v))
+        )
+        if seq_pass:
+            # one ratio per sample, still one pass over the logits: the workgroups of a sample exchange their
+            # log-ratios inside the launch; rows the launch leaves out (`pending`: samples too long to be resident
+            # together, waits that ran out) are written by a second pass over those rows only
+            dlogits = torch.empty((1, t, v), dtype=logits.dtype, device=dev)
+            pending = torch.empty(t, dtype=torch.uint8, device=dev)
+            ws_bytes = int(lib.prl_policy_rows_seq_workspace_bytes(t))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            with C.on_device(dev):
+                with C.timed("prl_policy_rows_seq_fwd_bwd", dev):
+                    C.check(
+                        lib.prl_policy_rows_seq_fwd_bwd(
+                            C.ptr(logits), code, t, v, logits.stride(1), C.ptr(ids), C.ptr(pos), C.ptr(adv),
+                            C.ptr(old), C.ptr(mask), int(bool(skip_masked)), temperature, length_norm, clip,
+                            float(loss_scale), at(0), at(1), at(2), C.ptr(dlogits), code, v, C.ptr(pending),
+                            seq_limits[0], seq_limits[1], C.ptr(ws), ws_bytes, st,
+                        ),
+                        "prl_policy_rows_seq_fwd_bwd",
+                    )
+                with C.timed("prl_policy_tail", dev):
+                    C.check(
+                        lib.prl_policy_tail(
+                            C.ptr(pos), at(0), C.ptr(old), C.ptr(adv), C.ptr(mask), t, ratio_code, length_norm, clip,
+                            float(loss_scale), at(8), at(4), at(5), at(6), at(3), at(7), None, C.c_void_p(ip),
+                            C.c_void_p(ip + 8 * (t + 1)), st,
+                        ),
+                        "prl_policy_tail",
+                    )
+                with C.timed("prl_logprob_bwd_selected", dev):
+                    C.check(
+                        lib.prl_logprob_bwd_selected(
+                            C.ptr(logits), code, t, v, logits.stride(1), C.ptr(ids), at(2), at(3), None, temperature,
+                            1, C.ptr(dlogits), code, v, C.ptr(pending), st,
+                        ),
+                        "prl_logprob_bwd_selected",
+                    )
+            ctx.dlogits = dlogits
+            _LAST_SEQ_PENDING[0] = pending
+        elif single_pass:
             dlogits = torch.empty((1, t, v), dtype=logits.dtype, device=dev)
             with C.on_device(dev):
                 with C.timed("prl_policy_rows_fwd_bwd", dev):
@@ -418,6 +479,7 @@ class _PolicyLoss(torch.autograd.Function):
         ratio, clipped, is_clipped = parts[4][:n_aux], parts[5][:n_aux], parts[6][:n_aux]
         seg_start = iarena[: t + 1]
         n_seg = iarena[t + 1 :].view(torch.int32)[:1]
+        single_pass = single_pass or seq_pass  # either way the gradient exists already and backward hands it out
         ctx.single_pass = single_pass
         if not single_pass:
             ctx.save_for_backward(logits, ids.view(1, t), lse, g)
@@ -484,7 +546,9 @@ def policy_loss(
     With `ratio_type = "token"`, bf16 logits that require a gradient and a
     vocabulary of at most 155648 the logits are read exactly once: the same
     pass that scores a row writes its gradient, and `.backward()` only hands
-    it on.  In every other case `.backward()` runs one more pass over the logits."""
+    it on.  The same holds for `ratio_type = "sequence"`: the workgroups of a sample exchange their log-ratios
+    inside the launch (rows of samples longer than ~224 tokens, and rows whose wait ran out, take a second pass
+    over those rows only).  In every other case `.backward()` runs one more pass over the logits."""
     if logits.ndim != 3 or logits.shape[0] != 1:
         raise ValueError(f"policy_loss takes one packed row, logits [1, T, V]; got {tuple(logits.shape)}")
     loss, lp, ent, ratio, clipped, is_clipped, seg_start, n_seg = _PolicyLoss.apply(

@@ -1,0 +1,75 @@
+"""Sequence-mode policy_loss + backward at the benchmark shape (T = 2048, V = 151936, bf16, 16 samples of 128
+tokens, every token unmasked): the one-pass kernel (workgroups of a sample exchange their log-ratios) against
+the two passes it replaces (PRL_SEQ_ROWS=0), rounds in random order over rotating logits buffers.
+
+    python3 tools/seq_mode_bench.py [sample length]
+"""
+from __future__ import annotations
+
+import os
+import random
+import statistics
+import sys
+from pathlib import Path
+
+import torch
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO))
+import prime_rl_cse_amd as prl  # noqa: E402
+from prime_rl_cse_amd import loss as L  # noqa: E402
+
+
+def main() -> None:
+    length = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+    t, v, dev = 2048, 151936, torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(0)
+    bufs = []
+    for _ in range(3):
+        x = torch.empty(1, t, v, dtype=torch.bfloat16, device=dev)
+        for r in range(0, t, 512):
+            x[0, r : r + 512] = (torch.randn(512, v, generator=g, device=dev) * 2.5).to(torch.bfloat16)
+        bufs.append(x)
+    ids = torch.randint(0, v, (1, t), generator=g, device=dev)
+    pos = torch.arange(length).repeat(t // length + 1)[:t].unsqueeze(0).to(dev)
+    adv = torch.randn(1, t, generator=g, device=dev)
+    old = torch.full((1, t), -12.0, device=dev)
+    mask = torch.ones(1, t, dtype=torch.bool, device=dev)
+    cfg = prl.LossConfig(ratio_type="sequence", ratio_length_norm=True)
+    unit = prl.unit_gradient(dev)
+    variants = {"two passes": "0", "one pass": "1"}
+    count = [0]
+
+    def run(flag: str) -> None:
+        os.environ["PRL_SEQ_ROWS"] = flag
+        x = bufs[count[0] % 3].requires_grad_(True)
+        count[0] += 1
+        x.grad = None
+        loss, _ = prl.policy_loss(x, ids, pos, adv, old, mask, 1.0, cfg, t // length)
+        loss.backward(unit)
+
+    times = {k: [] for k in variants}
+    order = list(variants)
+    for k in order:
+        run(variants[k])
+    torch.cuda.synchronize()
+    for _ in range(15):
+        random.shuffle(order)
+        for k in order:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(4):
+                run(variants[k])
+            b.record()
+            torch.cuda.synchronize()
+            times[k].append(a.elapsed_time(b) / 4)
+    run("1")
+    torch.cuda.synchronize()
+    print(f"samples of {length} tokens; rows left to the second pass in the last one-pass call: "
+          f"{int(L._LAST_SEQ_PENDING[0].sum())} of {t}")
+    for k, ts in sorted(times.items(), key=lambda kv: statistics.median(kv[1])):
+        print(f"{k:12s} median {statistics.median(ts) * 1e3:7.1f} us  min {min(ts) * 1e3:7.1f} us", flush=True)
+
+
+if __name__ == "__main__":
+    main()
