@@ -389,3 +389,33 @@ def test_sequence_rows_kernel_full_size_through_policy_loss(monkeypatch):
     assert pending[long_rows].all()
     # (a short sample's row may take the second pass too if its wait ran out; on an idle GPU none does)
     assert int(pending[~long_rows].sum()) == 0
+
+
+def test_sequence_rows_kernel_beside_other_work_on_the_gpu():
+    """The same call while another stream keeps the compute units busy with matrix products: workgroups of a
+    sample may then not all be resident together, waits may run out and rows go to the second pass; whichever
+    rows do, the results are the oracle's."""
+    lengths = [120, 60, 200, 33, 90, 150, 10, 180]
+    vocab, temp = 32768, 1.0
+    logits, ids, pos, mask, adv, old = seeded_case(23, lengths, 0, vocab, temp, mask_p=0.8)
+    cfg = O.LossConfig("sequence", False, 8.0)
+    b = lambda x: x.unsqueeze(0)
+    want = O.policy_epilogue(logits, b(ids), b(pos), b(adv), b(old), b(mask), temp, cfg, len(lengths))
+    args = (logits[0].to(DEV), ids.to(DEV), pos.to(DEV), adv.to(DEV), old.to(DEV), mask.to(DEV), temp, False, 8.0,
+            len(lengths), True)
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device=DEV, dtype=torch.bfloat16)
+    torch.cuda.synchronize()
+    seen = []
+    for spins in (4096, 64, 2):
+        with torch.cuda.stream(side):
+            for _ in range(40):
+                a @ a
+        lp, ent, d, loss, ratio, n, pending = _seq_call(*args, 224, spins)
+        side.synchronize()
+        seen.append(int(pending.sum()))
+        close(lp.cpu()[mask], want["logprobs"][0][mask])
+        close(loss[0], want["loss"])
+        close(ratio[:n], want["importance_ratio"])
+        assert bf16_ulp_close(d.cpu(), want["dlogits"][0], ulps=1, atol=1e-9)
+    print("rows left to the second pass beside a busy stream, by wait length:", seen)
