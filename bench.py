@@ -399,9 +399,14 @@ def launch_ranks(n: int, argv: list[str], grace: float = 30.0) -> int:
     import subprocess
 
     procs = []
-    for r, (cmd, env) in enumerate(rank_commands(n, argv, free_port())):
-        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr,
-                                      stderr=sys.stderr, text=True))
+    try:
+        for r, (cmd, env) in enumerate(rank_commands(n, argv, free_port())):
+            procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr,
+                                          stderr=sys.stderr, text=True))
+    except BaseException:  # a rank that could not be started: the ones that were must not be left waiting for it
+        for p in procs:
+            p.kill()
+        raise
 
     def relay() -> None:
         for text in procs[0].stdout:

@@ -1,0 +1,34 @@
+"""Many one-pass sequence-mode calls on changing ragged rows, each checked against the two-pass path."""
+import os, sys, torch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import prime_rl_cse_amd as prl
+from prime_rl_cse_amd import loss as L
+from tests.helpers import bf16_ulp_close
+dev = "cuda:0"
+gen = torch.Generator().manual_seed(1)
+v = 32768
+bad = 0; pend = 0
+for it in range(60):
+    lens = torch.randint(2, 220, (int(torch.randint(3, 14, (1,), generator=gen)),), generator=gen).tolist()
+    t = sum(lens)
+    pos = torch.cat([torch.arange(n) for n in lens])[None]
+    ids = torch.randint(0, v, (1, t), generator=gen)
+    mask = torch.rand(1, t, generator=gen) < 0.7
+    logits = (torch.randn(1, t, v, generator=gen) * 3).to(torch.bfloat16).to(dev)
+    adv = torch.randn(1, t, generator=gen).to(dev); old = (-10.5 + 0.3 * torch.randn(1, t, generator=gen)).to(dev)
+    cfg = prl.LossConfig(ratio_type="sequence", ratio_length_norm=bool(it % 2), clip_ratio=3.0)
+    outs = []
+    for flag in ("0", "1"):
+        os.environ["PRL_SEQ_ROWS"] = flag
+        x = logits.detach().clone().requires_grad_(True)
+        loss, aux = prl.policy_loss(x, ids.to(dev), pos.to(dev), adv, old, mask.to(dev), 0.9, cfg, len(lens), skip_masked=bool(it % 3))
+        loss.backward()
+        outs.append((loss.item(), aux["logprobs"].cpu(), x.grad.cpu()))
+    pend += int(L._LAST_SEQ_PENDING[0].sum())
+    (l0, p0, g0), (l1, p1, g1) = outs
+    ok = abs(l0 - l1) <= 1e-5 * max(1, abs(l0)) and (p0 - p1).abs().max() < 1e-5 and bf16_ulp_close(g1, g0, ulps=1, atol=1e-10)
+    if not ok:
+        bad += 1
+        print("mismatch at", it, lens, l0, l1, (p0 - p1).abs().max().item(), flush=True)
+print(f"seq stress: 60 rows, mismatches {bad}, rows left to the second pass in total {pend}")
+sys.exit(1 if bad else 0)
