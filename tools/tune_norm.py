@@ -9,7 +9,7 @@ REPO = Path(__file__).resolve().parent.parent
 CSRC = REPO / "prime-rl-cse_amd" / "csrc"
 LIB = REPO / "prime-rl-cse_amd" / "lib"
 TUNE = LIB / "tune"
-CAPS = (64, 128, 256, 512, 1024)
+CAPS = (128, 256, 512, 1024, 2048, 4096)
 
 
 def build():
@@ -34,7 +34,7 @@ def run():
     from prime_rl_cse_amd import _capi as C
     dev = torch.device("cuda:0")
     st = C.stream_ptr(dev)
-    for rows, h in ((2048, 1024), (32768, 128), (16384, 128)):
+    for rows, h in ((16384, 1024), (2048, 1024), (32768, 128), (16384, 128), (262144, 128)):
         x = torch.randn(rows, h, device=dev).to(torch.bfloat16)
         w = torch.ones(h, device=dev, dtype=torch.bfloat16)
         gy = torch.randn(rows, h, device=dev).to(torch.bfloat16)
@@ -51,12 +51,12 @@ def run():
 
         def fwd(cap):
             lib, _ = libs[cap]
-            assert lib.prl_rmsnorm_fwd(C.ptr(x), h, C.ptr(w), C.ptr(y), h, C.ptr(rstd), C.PRL_BF16, rows, h, 1e-6, st) == 0
+            assert lib.prl_rmsnorm_fwd(C.ptr(x), h, C.ptr(w), C.ptr(y), h, C.ptr(rstd), C.PRL_BF16, rows, h, 1e-6, 0, 0, st) == 0
 
         def bwd(cap):
             lib, ws = libs[cap]
             assert lib.prl_rmsnorm_bwd(C.ptr(x), h, C.ptr(w), C.ptr(rstd), C.ptr(gy), h, C.ptr(gx), h, C.ptr(gw), C.PRL_BF16,
-                                       rows, h, C.ptr(ws), ws.numel(), st) == 0
+                                       rows, h, C.ptr(ws), ws.numel(), 0, 0, st) == 0
 
         for name, fn in (("fwd", fwd), ("bwd", bwd)):
             times = {cap: [] for cap in CAPS}
