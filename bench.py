@@ -535,8 +535,9 @@ def main(argv: list[str] | None = None) -> int:
 
     # inside the timed region only the dominant kernel carries events (every event pair costs a few
     # microseconds of queue time); the other kernels are timed in a short untimed pass afterwards
-    # ... and of its launches one in three (with 8 per step, a sample that walks over all 8 rows)
-    timer = _capi.KernelTimer(only={"prl_logprob_bwd", "prl_policy_rows_fwd_bwd"}, every=3)
+    # ... and of its launches one in seven (with 8 per step, a sample that walks over all 8 rows; an event pair
+    # holds the queue up for ~11 us, which at one in three was 1.6 % of the step)
+    timer = _capi.KernelTimer(only={"prl_logprob_bwd", "prl_policy_rows_fwd_bwd"}, every=7)
     _capi.set_timer(timer)
     if world > 1:
         dist.barrier()
