@@ -2,7 +2,7 @@
 tokens, every token unmasked): the one-pass kernel (workgroups of a sample exchange their log-ratios) against
 the two passes it replaces (PRL_SEQ_ROWS=0), rounds in random order over rotating logits buffers.
 
-    python3 tools/seq_mode_bench.py [sample length]
+    python3 tools/seq_mode_bench.py [sample length | ragged]      (ragged: samples of 11 .. 128 tokens, seeded)
 """
 from __future__ import annotations
 
@@ -21,7 +21,8 @@ from prime_rl_cse_amd import loss as L  # noqa: E402
 
 
 def main() -> None:
-    length = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+    ragged = len(sys.argv) > 1 and sys.argv[1] == "ragged"
+    length = 128 if ragged or len(sys.argv) < 2 else int(sys.argv[1])
     t, v, dev = 2048, 151936, torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(0)
     bufs = []
@@ -31,7 +32,17 @@ def main() -> None:
             x[0, r : r + 512] = (torch.randn(512, v, generator=g, device=dev) * 2.5).to(torch.bfloat16)
         bufs.append(x)
     ids = torch.randint(0, v, (1, t), generator=g, device=dev)
-    pos = torch.arange(length).repeat(t // length + 1)[:t].unsqueeze(0).to(dev)
+    if ragged:
+        rng, parts, left = random.Random(7), [], t
+        while left > 0:
+            n = min(rng.randint(11, 128), left)
+            parts.append(torch.arange(n))
+            left -= n
+        pos = torch.cat(parts).unsqueeze(0).to(dev)
+        n_samples = len(parts)
+    else:
+        pos = torch.arange(length).repeat(t // length + 1)[:t].unsqueeze(0).to(dev)
+        n_samples = t // length
     adv = torch.randn(1, t, generator=g, device=dev)
     old = torch.full((1, t), -12.0, device=dev)
     mask = torch.ones(1, t, dtype=torch.bool, device=dev)
@@ -45,7 +56,7 @@ def main() -> None:
         x = bufs[count[0] % 3].requires_grad_(True)
         count[0] += 1
         x.grad = None
-        loss, _ = prl.policy_loss(x, ids, pos, adv, old, mask, 1.0, cfg, t // length)
+        loss, _ = prl.policy_loss(x, ids, pos, adv, old, mask, 1.0, cfg, n_samples)
         loss.backward(unit)
 
     times = {k: [] for k in variants}
@@ -65,7 +76,7 @@ def main() -> None:
             times[k].append(a.elapsed_time(b) / 4)
     run("1")
     torch.cuda.synchronize()
-    print(f"samples of {length} tokens; rows left to the second pass in the last one-pass call: "
+    print(f"{'ragged samples of 11-128' if ragged else 'samples of ' + str(length)} tokens; rows left to the second pass in the last one-pass call: "
           f"{int(L._LAST_SEQ_PENDING[0].sum())} of {t}")
     for k, ts in sorted(times.items(), key=lambda kv: statistics.median(kv[1])):
         print(f"{k:12s} median {statistics.median(ts) * 1e3:7.1f} us  min {min(ts) * 1e3:7.1f} us", flush=True)
