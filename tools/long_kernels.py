@@ -1,3 +1,8 @@
+"""Kernels longer than 1 ms among the last 3200 of a rocprofv3 kernel trace (the LM-head products, the row kernel
+and the optimizer of a trainer step), with their durations.
+
+    python3 tools/long_kernels.py <dir with *kernel_trace.csv>
+"""
 import csv, glob, sys
 rows = []
 for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
