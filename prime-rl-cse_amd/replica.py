@@ -56,7 +56,7 @@ def _round_up(n: int, a: int) -> int:
     return (n + a - 1) // a * a
 
 
-_LAYER = re.compile(r"^(.*\.layers\.\d+)\.")  # parameters of one transformer block share this prefix
+_LAYER = re.compile(r"^((?:.*\.)?layers\.\d+)\.")  # parameters of one transformer block share this prefix
 
 
 def bucket_plan(names: list[str], numel: list[int], bucket_elems: int | None) -> list[tuple[int, int]]:

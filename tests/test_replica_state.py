@@ -240,3 +240,66 @@ def test_bucketed_exchange_gives_the_step_of_the_single_exchange_over_gloo():
         assert norms2 == pytest.approx(norms1, rel=1e-6) and same
         norms1, norms2, same, close = out[0.5]
         assert norms2 == pytest.approx(norms1, rel=1e-6) and close
+
+
+class _Stack(nn.Module):
+    """Parameters with the names a transformer has (an embedding, numbered blocks, a final norm), odd sizes."""
+
+    def __init__(self, blocks: int, width: int):
+        super().__init__()
+        self.embed_tokens = nn.Embedding(53, width)
+        self.layers = nn.ModuleList(
+            nn.ModuleDict({"attn": nn.Linear(width, width + 3), "norm": nn.LayerNorm(width), "mlp": nn.Linear(width, 7)})
+            for _ in range(blocks))
+        self.norm = nn.LayerNorm(width)
+
+
+@__import__("pytest").mark.parametrize("world", [2, 3, 8])
+@__import__("pytest").mark.parametrize("bucket_bytes", [None, 4 * 700, 4 * 5000])
+def test_layout_of_rank_counts_that_never_run_here(world, bucket_bytes, monkeypatch):
+    """What every rank of a W-rank job lays out, built one rank after the other in this process (the layout is
+    made without any collective): the buckets tile the flat buffers, every bucket splits evenly over the ranks,
+    the ranks' master shards put together are exactly the parameters, and nobody's shard overlaps another's."""
+    import torch.distributed as dist
+
+    states, models = [], []
+    for rank in range(world):
+        monkeypatch.setattr(dist, "is_initialized", lambda: True)
+        monkeypatch.setattr(dist, "get_world_size", lambda group=None: world)
+        monkeypatch.setattr(dist, "get_rank", lambda group=None, rank=rank: rank)
+        torch.manual_seed(3)
+        model = _Stack(blocks=5, width=29)
+        if rank == 0:
+            values = [p.detach().clone() for p in model.parameters()]
+        states.append(FlatState(model, None, torch.float32, bucket_bytes))
+        models.append(model)
+    first = states[0]
+    assert all(s.total == first.total and s.offsets == first.offsets and s.shard == first.shard for s in states)
+    assert first.total == world * first.shard
+    # buckets: back to back, whole blocks, every one a multiple of ALIGN elements per rank
+    assert first.buckets[0].lo == 0 and first.buckets[-1].hi == first.total
+    for a, b in zip(first.buckets, first.buckets[1:]):
+        assert a.hi == b.lo and a.last == b.first
+    for b in first.buckets:
+        assert (b.hi - b.lo) == world * b.shard and b.shard % ALIGN == 0
+        block_of = {n.split(".")[1] for n in first.names[b.first : b.last] if n.startswith("layers.")}
+        for other in first.buckets:
+            if other is not b:
+                assert not block_of & {n.split(".")[1] for n in first.names[other.first : other.last]
+                                       if n.startswith("layers.")}
+    if bucket_bytes is not None and bucket_bytes < 4 * 5000:
+        assert len(first.buckets) > 2
+    # the shards of all ranks, put where `owned_ranges` says, give the flat fp32 parameters exactly once
+    flat = torch.full((first.total,), float("nan"))
+    covered = torch.zeros(first.total, dtype=torch.int32)
+    for s in states:
+        for lo, hi, m_lo in s.owned_ranges():
+            flat[lo:hi] = s.master.detach()[m_lo : m_lo + hi - lo]
+            covered[lo:hi] += 1
+    assert bool((covered == 1).all())
+    for v, o, n in zip(values, first.offsets, first.numel):
+        assert torch.equal(flat[o : o + n], v.reshape(-1))
+    pad = torch.ones(first.total, dtype=torch.bool)
+    for o, n in zip(first.offsets, first.numel):
+        pad[o : o + n] = False
+    assert not flat[pad].any()
