@@ -123,7 +123,8 @@ class FlatState:
     and its new weights can be all-gathered while the next forward is already running on earlier buckets.  The
     master shard is the concatenation of the rank's parts of all buckets.  With one bucket (the default) the
     layout is "rank r owns elements [r * n / W, (r + 1) * n / W)".  AdamW and SGD are element-wise, and every
-    element's gradient is the same sum over ranks whatever bucket it is in, so bucketing changes no value.
+    element's gradient is the sum over ranks whatever bucket it is in, so bucketing changes no value beyond the
+    order in which the collective adds the ranks' contributions (one order only with two ranks).
     """
 
     def __init__(self, model: nn.Module, group: Any = None, compute_dtype: torch.dtype = torch.bfloat16,
