@@ -341,13 +341,15 @@ _LAST_SEQ_PENDING: list[Tensor | None] = [None]
 def _seq_rows_limits() -> tuple[int, int] | None:
     """(longest sample whose workgroups wait for each other, sweeps a workgroup waits) of the one-pass
     sequence-mode kernel, or None when it is switched off (PRL_SEQ_ROWS=0).  PRL_SEQ_ROWS_MAX_LEN (224: a launch
-    has one workgroup per compute unit, 256 of them, resident at a time) and PRL_SEQ_ROWS_SPINS (4096 sweeps of
-    about a microsecond) override the defaults; rows the kernel leaves out go through the second-pass kernel."""
+    has one workgroup per compute unit, 256 of them, resident at a time) and PRL_SEQ_ROWS_SPINS (512 sweeps of one
+    to two microseconds: with nothing else on the GPU every wait ends within 64-256 sweeps, and a workgroup whose
+    sample cannot become resident, e.g. beside another process's kernels, gives its compute unit up after under a
+    millisecond) override the defaults; rows the kernel leaves out go through the second-pass kernel."""
     import os
 
     if os.environ.get("PRL_SEQ_ROWS", "1") == "0":
         return None
-    return int(os.environ.get("PRL_SEQ_ROWS_MAX_LEN", "224")), int(os.environ.get("PRL_SEQ_ROWS_SPINS", "4096"))
+    return int(os.environ.get("PRL_SEQ_ROWS_MAX_LEN", "224")), int(os.environ.get("PRL_SEQ_ROWS_SPINS", "512"))
 
 
 def _rows_kernel_enabled() -> bool:
