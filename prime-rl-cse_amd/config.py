@@ -1,34 +1,35 @@
-"""Loss configuration with the reference's field names and defaults
-(src/prime_rl/trainer/rl/config.py:19-27)."""
+"""The two small schemas the hot path reads: how the loss is formed, and the shape of synthetic micro-batches.
+Field names, bounds and defaults are the reference's (src/prime_rl/trainer/rl/config.py:19-43), because its TOML
+recipes are loaded as they are."""
 
 from __future__ import annotations
 
 from typing import Literal
 
-from pydantic import BaseModel, Field
-from typing_extensions import Annotated
+from pydantic import BaseModel, Field, model_validator
 
 
 class LossConfig(BaseModel):
-    """Base config for loss."""
+    """`ratio_type`: one importance ratio per token, or one per sample (its tokens' summed log-ratio);
+    `ratio_length_norm`: divide that sum by the sample's number of scored tokens (sequence mode only);
+    `clip_ratio`: upper clamp of the ratio, not below 0."""
 
-    ratio_type: Annotated[Literal["token", "sequence"], Field(description="Type of importance ratio to use.")] = "token"
-    ratio_length_norm: Annotated[
-        bool, Field(description="Whether to normalize the importance ratio by the sequence length.")
-    ] = False
-    clip_ratio: Annotated[float, Field(ge=0)] = 8.0
+    ratio_type: Literal["token", "sequence"] = "token"
+    ratio_length_norm: bool = False
+    clip_ratio: float = Field(default=8.0, ge=0)
 
 
 class FakeDataLoaderConfig(BaseModel):
-    """Synthetic micro-batches for debugging and benchmarks
-    (src/prime_rl/trainer/rl/config.py:30-43)."""
+    """Synthetic rollouts: `batch_size` samples of `seq_len` tokens per step, `micro_batch_size` of them packed
+    into a row (all at least 1; a step holds whole rows)."""
 
-    micro_batch_size: Annotated[int, Field(ge=1)] = 1
-    batch_size: Annotated[int, Field(ge=1)] = 2
-    seq_len: Annotated[int, Field(ge=1)] = 128
+    micro_batch_size: int = Field(default=1, ge=1)
+    batch_size: int = Field(default=2, ge=1)
+    seq_len: int = Field(default=128, ge=1)
 
-    def model_post_init(self, _ctx) -> None:
-        if self.batch_size % self.micro_batch_size != 0:
-            raise ValueError("Batch size must be divisible by micro batch size")
-        if self.batch_size < self.micro_batch_size:
-            raise ValueError("Batch size must be greater than or equal to micro batch size")
+    @model_validator(mode="after")
+    def _whole_rows(self) -> "FakeDataLoaderConfig":
+        if self.batch_size < self.micro_batch_size or self.batch_size % self.micro_batch_size:
+            raise ValueError(f"batch_size {self.batch_size} is not a positive multiple of micro_batch_size "
+                             f"{self.micro_batch_size}")
+        return self
