@@ -380,6 +380,26 @@ int prl_attn_short_bwd(const void* q, const int64_t* q_strides, const void* k, c
                        int32_t q_heads, int32_t kv_heads, float scale, void* stream);
 
 /*
+ * The same attention for samples of ANY length (head dimension 128, bf16), tiled flash-style over 128 x 128
+ * blocks of the score matrix with a running soft-max; stands where the reference's recipes with long samples
+ * (wordle: 4096 tokens, hendrycks_math: 2048, deepscaler: 8192) run flash-attn's variable-length kernel
+ * (src/prime_rl/trainer/model.py:58-60, :251-254).  Arguments as prl_attn_short_*; `max_len` is the longest
+ * sample of the table (HOST value; it sizes the grid: a longer sample than stated would be cut off there, never
+ * followed out of bounds).
+ */
+int prl_attn_long_supported(int dtype, int64_t head_dim, int64_t max_len, int64_t q_heads, int64_t kv_heads);
+int prl_attn_long_fwd(const void* q, const int64_t* q_strides, const void* k, const int64_t* k_strides,
+                      const void* v, const int64_t* v_strides, void* out, const int64_t* out_strides, float* lse2,
+                      const int32_t* cu_seqlens, int32_t n_samples, int64_t max_len, int64_t T, int32_t q_heads,
+                      int32_t kv_heads, float scale, void* stream);
+int prl_attn_long_bwd(const void* q, const int64_t* q_strides, const void* k, const int64_t* k_strides,
+                      const void* v, const int64_t* v_strides, const void* out, const int64_t* out_strides,
+                      const void* dout, const int64_t* dout_strides, const float* lse2, float* delta, void* dq,
+                      const int64_t* dq_strides, void* dk, const int64_t* dk_strides, void* dv,
+                      const int64_t* dv_strides, const int32_t* cu_seqlens, int32_t n_samples, int64_t max_len,
+                      int64_t T, int32_t q_heads, int32_t kv_heads, float scale, void* stream);
+
+/*
  * AdamW over one flat fp32 shard, fused with what surrounds it at the end of a step: param, exp_avg, exp_avg_sq
  * and grad are fp32 [n] (n a multiple of 4); every gradient is first multiplied by grad_scale[0] (DEVICE
  * memory, NULL = 1: the clipping factor of clip_grad_norm_, never copied to the host); `compute_copy`

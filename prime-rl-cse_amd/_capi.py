@@ -109,6 +109,19 @@ SIGNATURES = {
          POINTER(c_int64), c_void_p, POINTER(c_int64), c_void_p, c_int32, c_int64, c_int32, c_int32, c_float,
          c_void_p],
     ),
+    "prl_attn_long_supported": (c_int, [c_int, c_int64, c_int64, c_int64, c_int64]),
+    "prl_attn_long_fwd": (
+        c_int,
+        [c_void_p, POINTER(c_int64), c_void_p, POINTER(c_int64), c_void_p, POINTER(c_int64), c_void_p,
+         POINTER(c_int64), c_void_p, c_void_p, c_int32, c_int64, c_int64, c_int32, c_int32, c_float, c_void_p],
+    ),
+    "prl_attn_long_bwd": (
+        c_int,
+        [c_void_p, POINTER(c_int64), c_void_p, POINTER(c_int64), c_void_p, POINTER(c_int64), c_void_p,
+         POINTER(c_int64), c_void_p, POINTER(c_int64), c_void_p, c_void_p, c_void_p, POINTER(c_int64), c_void_p,
+         POINTER(c_int64), c_void_p, POINTER(c_int64), c_void_p, c_int32, c_int64, c_int64, c_int32, c_int32, c_float,
+         c_void_p],
+    ),
     "prl_swiglu_rows_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p]),
     "prl_swiglu_rows_bwd": (
         c_int,

@@ -157,6 +157,79 @@ class _AttnShort(torch.autograd.Function):
         return dq, dk, dv, None, None, None
 
 
+class _AttnLong(torch.autograd.Function):
+    """The same for samples of any length (`prl_attn_long_fwd` / `_bwd`: flash-style tiles with a running
+    soft-max); `lmax` is the longest sample of the table."""
+
+    @staticmethod
+    def forward(ctx, q: Tensor, k: Tensor, v: Tensor, cu: Tensor, n: int, lmax: int, scale: float):
+        from . import _capi as C
+
+        dev = C.require_device(q, k, v, cu)
+        lib = C.load()
+        q, k, v = _kernel_ready(q), _kernel_ready(k), _kernel_ready(v)
+        _, hq, t, d = q.shape
+        hkv = k.shape[1]
+        out = torch.empty((1, t, hq, d), dtype=q.dtype, device=dev)
+        lse2 = torch.empty((hq, t), dtype=torch.float32, device=dev)
+        ov = out.transpose(1, 2)
+        with C.on_device(dev), C.timed("prl_attn_long_fwd", dev):
+            C.check(
+                lib.prl_attn_long_fwd(C.ptr(q), _strides2(q), C.ptr(k), _strides2(k), C.ptr(v), _strides2(v),
+                                      C.ptr(out), _strides2(ov), C.ptr(lse2), C.ptr(cu), n, lmax, t, hq, hkv, scale,
+                                      C.stream_ptr(dev)),
+                "prl_attn_long_fwd",
+            )
+        ctx.save_for_backward(q, k, v, out, lse2, cu)
+        ctx.n, ctx.lmax, ctx.scale = n, lmax, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: Tensor):
+        from . import _capi as C
+
+        q, k, v, out, lse2, cu = ctx.saved_tensors
+        dev = q.device
+        lib = C.load()
+        _, hq, t, d = q.shape
+        hkv = k.shape[1]
+        do = _kernel_ready(dout.transpose(1, 2))
+        ov = out.transpose(1, 2)
+        dq = torch.empty((1, t, hq, d), dtype=q.dtype, device=dev).transpose(1, 2)
+        dk = torch.empty((1, t, hkv, d), dtype=q.dtype, device=dev).transpose(1, 2)
+        dv = torch.empty((1, t, hkv, d), dtype=q.dtype, device=dev).transpose(1, 2)
+        delta = torch.empty((hq, t), dtype=torch.float32, device=dev)
+        with C.on_device(dev), C.timed("prl_attn_long_bwd", dev):
+            C.check(
+                lib.prl_attn_long_bwd(C.ptr(q), _strides2(q), C.ptr(k), _strides2(k), C.ptr(v), _strides2(v),
+                                      C.ptr(ov), _strides2(ov), C.ptr(do), _strides2(do), C.ptr(lse2), C.ptr(delta),
+                                      C.ptr(dq), _strides2(dq), C.ptr(dk), _strides2(dk), C.ptr(dv), _strides2(dv),
+                                      C.ptr(cu), ctx.n, ctx.lmax, t, hq, hkv, ctx.scale, C.stream_ptr(dev)),
+                "prl_attn_long_bwd",
+            )
+        return dq, dk, dv, None, None, None, None
+
+
+def long_attention_supported(query: Tensor, key: Tensor, plan: "PackedPlan") -> bool:
+    """Samples of any length through this package's tiled kernels (PRL_ATTN_LONG=0: leave them to torch)."""
+    import os
+
+    if plan.cu is None or not query.is_cuda or query.dtype != torch.bfloat16 \
+            or os.environ.get("PRL_ATTN_LONG", "1") == "0":
+        return False
+    from . import _capi as C
+
+    return bool(C.load().prl_attn_long_supported(C.dtype_code(query), query.shape[3], plan.lmax, query.shape[1],
+                                                 key.shape[1]))
+
+
+def long_attention(query: Tensor, key: Tensor, value: Tensor, plan: "PackedPlan", scaling: float | None = None):
+    """Causal attention within every sample of a packed row, samples of any length; [1, heads, T, 128] in,
+    [1, T, heads, 128] out."""
+    scale = float(scaling) if scaling is not None else float(query.shape[3]) ** -0.5
+    return _AttnLong.apply(query, key, value, plan.cu, plan.n, plan.lmax, scale)
+
+
 def _varlen_attn():
     """PyTorch's variable-length attention, or None (older torch, or PRL_ATTN_VARLEN=0 for A/B measurements)."""
     import os
@@ -260,6 +333,8 @@ def packed_sdpa_attention(module: Any, query: Tensor, key: Tensor, value: Tensor
                            **kwargs)
     if short_attention_supported(query, key, plan):
         return short_attention(query, key, value, plan, scaling), None
+    if long_attention_supported(query, key, plan):
+        return long_attention(query, key, value, plan, scaling), None
     if varlen_attention_supported(query, plan, scaling):
         return varlen_attention(query, key, value, plan), None
     if not plan.side_by_side:
