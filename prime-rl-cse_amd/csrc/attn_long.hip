@@ -298,6 +298,9 @@ __global__ __launch_bounds__(kAThreads, 2) void k_attn_long_bwd_dq(AttnView q, A
 #ifndef PRL_ATTN_DKV_SPLIT
 #define PRL_ATTN_DKV_SPLIT 1
 #endif
+#ifndef PRL_ATTN_DKV_ROUNDS
+#define PRL_ATTN_DKV_ROUNDS 2
+#endif
 template <int DSPLIT>
 __global__ __launch_bounds__(kAThreads, 2) void k_attn_long_bwd_dkv(AttnView q, AttnView k, AttnView v,
                                                                     AttnView dout, const float* lse2,
@@ -339,12 +342,21 @@ __global__ __launch_bounds__(kAThreads, 2) void k_attn_long_bwd_dkv(AttnView q, 
     for (int qt = kt; qt < nqt; ++qt) {
       const int q0 = qt * kAL;
       __syncthreads();  // the previous images are no longer read
+#if PRL_ATTN_DKV_ROUNDS == 1
+      {  // both images in one round of loads (64 registers in flight)
+        uint16_t* const imgs[2] = {Qs, Os};
+        const AttnView* const views[2] = {&q, &dout};
+        const int hs[2] = {hq, hq};
+        stage_tile<2>(imgs, views, start, len, q0, hs);
+      }
+#else
       for (int j = 0; j < 2; ++j) {  // one image per round of loads: registers are scarce here
         uint16_t* const imgs[1] = {j ? Os : Qs};
         const AttnView* const views[1] = {j ? &dout : &q};
         const int hs[1] = {hq};
         stage_tile<1>(imgs, views, start, len, q0, hs);
       }
+#endif
       if (threadIdx.x < kAL) {
         const bool in = q0 + (int)threadIdx.x < len;
         row_lse[threadIdx.x] = in ? lse2[(int64_t)hq * T + start + q0 + threadIdx.x] : 0.0f;
@@ -365,13 +377,21 @@ __global__ __launch_bounds__(kAThreads, 2) void k_attn_long_bwd_dkv(AttnView q, 
             sa = mfma(frag_rows(Qs, 32 * mt + r, kk, h), kf[kk], sa);  // S: rows = queries, lane = key
             dp = mfma(frag_rows(Os, 32 * mt + r, kk, h), vf[kk], dp);  // dP = dO V^T
           }
+          // log-sum-exp and delta of the 16 query rows this lane half holds (rows 8j + 4h .. + 3, j = 0 .. 3): four
+          // 16-byte reads each, and no branch around them.  Rows past the sample's end need no mask: their Q and dO
+          // rows are zero in the images, so P there multiplies zeros in dV and dS comes out as zero.
+          f32x4 lse_r[4], del_r[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            lse_r[j] = *reinterpret_cast<const f32x4*>(row_lse + 32 * mt + 8 * j + 4 * h);
+            del_r[j] = *reinterpret_cast<const f32x4*>(row_delta + 32 * mt + 8 * j + 4 * h);
+          }
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
-            const int qrow = 32 * mt + acc_row(i, h), query = q0 + qrow;
-            const bool valid = key <= query && query < len && key < len;
-            const float p = valid ? __builtin_amdgcn_exp2f(fmaf(sa[i], c, -row_lse[qrow])) : 0.0f;
+            float p = __builtin_amdgcn_exp2f(fmaf(sa[i], c, -lse_r[i >> 2][i & 3]));
+            if (diag) p = key <= q0 + 32 * mt + acc_row(i, h) ? p : 0.0f;  // causal, on the diagonal tile only
             sa[i] = p;
-            dp[i] = p * (dp[i] - row_delta[qrow]) * scale;  // dS
+            dp[i] = p * (dp[i] - del_r[i >> 2][i & 3]) * scale;  // dS
           }
 #pragma unroll
           for (int s2 = 0; s2 < 2; ++s2) {

@@ -259,13 +259,22 @@ __global__ __launch_bounds__(kAThreads, 2) void k_attn_short_bwd_dkv(AttnView q,
             sa = mfma(frag_rows(Qs, 32 * mt + r, kk, h), kf[kk], sa);  // S: rows = queries, lane = key
             dp = mfma(frag_rows(Os, 32 * mt + r, kk, h), vf[kk], dp);  // dP = dO V^T
           }
+          // log-sum-exp and delta of the 16 query rows this lane half holds (rows 8j + 4h .. + 3, j = 0 .. 3): four
+          // 16-byte reads each and no branch around them (a load inside the conditional made the compiler emit one
+          // branch and one LDS round trip per element).  Rows past the sample's end need no mask: their Q and dO
+          // rows are zero in the images, so P there multiplies zeros in dV and dS comes out as zero.
+          f32x4 lse_r[4], del_r[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            lse_r[j] = *reinterpret_cast<const f32x4*>(row_lse + 32 * mt + 8 * j + 4 * h);
+            del_r[j] = *reinterpret_cast<const f32x4*>(row_delta + 32 * mt + 8 * j + 4 * h);
+          }
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
-            const int query = 32 * mt + acc_row(i, h);
-            const bool valid = key <= query && query < len && key < len;
-            const float p = valid ? __builtin_amdgcn_exp2f(fmaf(sa[i], c, -row_lse[query])) : 0.0f;
+            float p = __builtin_amdgcn_exp2f(fmaf(sa[i], c, -lse_r[i >> 2][i & 3]));
+            p = key <= 32 * mt + acc_row(i, h) ? p : 0.0f;  // causal
             sa[i] = p;
-            dp[i] = p * (dp[i] - row_delta[query]) * scale;  // dS
+            dp[i] = p * (dp[i] - del_r[i >> 2][i & 3]) * scale;  // dS
           }
 #pragma unroll
           for (int s2 = 0; s2 < 2; ++s2) {

@@ -162,6 +162,25 @@ class WeightPublisher:
     def _views(buffer: Tensor, layout: list[tuple]) -> dict[str, Tensor]:
         return {name: buffer[off : off + n].view(shape) for name, shape, off, n in layout}
 
+    _pinned_refused = False  # set once pinned host memory has run out on this machine
+
+    @classmethod
+    def _host_buffer(cls, shape: Any, dtype: torch.dtype, zero: bool = False) -> Tensor:
+        """Host memory for a copy-out: pinned (the copy then runs beside the compute stream), or, once the machine
+        refuses to pin more (its locked-memory limit, not this process's doing), ordinary memory: the copy then
+        holds the side stream up, the publication still happens."""
+        make = torch.zeros if zero else torch.empty
+        if not cls._pinned_refused:
+            try:
+                return make(shape, dtype=dtype, pin_memory=True)
+            except RuntimeError as exc:  # "HIP error: out of memory" from the pinning call
+                cls._pinned_refused = True
+                import logging
+
+                logging.getLogger(__name__).warning("weight publication: no more pinned host memory (%s); "
+                                                    "copying out through pageable memory from here on", exc)
+        return make(shape, dtype=dtype)
+
     def _host_slot(self, total: int, dtype: torch.dtype) -> Tensor:
         """A pinned buffer of `total` elements that no publication in flight is using (at most `max_in_flight`
         are, and `publish` has waited for the oldest): buffers are kept and reused, pinning memory costs more
@@ -172,7 +191,7 @@ class WeightPublisher:
         for buf in self._slots:
             if id(buf) not in busy and fits(buf):
                 return buf
-        buf = torch.zeros(total, dtype=dtype, pin_memory=True)  # zeros: the padding between slices is written too
+        buf = self._host_buffer(total, dtype, zero=True)  # zeros: the padding between slices is written too
         self._slots = [b for b in self._slots if id(b) in busy or fits(b)] + [buf]
         return buf
 
@@ -223,7 +242,7 @@ class WeightPublisher:
                     slot.copy_(flat, non_blocking=True)
                     on_host = self._views(slot, layout)
                     for k, v in others.items():  # the odd integer buffer: a tensor of its own
-                        buf = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
+                        buf = self._host_buffer(v.shape, v.dtype)
                         buf.copy_(v, non_blocking=True)
                         on_host[k] = buf
                     host = {k: on_host[k] for k in state}
@@ -249,7 +268,7 @@ class WeightPublisher:
                 if self._is_master:
                     for k, v in full.items():
                         if v.device.type == "cuda":
-                            buf = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
+                            buf = self._host_buffer(v.shape, v.dtype)
                             buf.copy_(v, non_blocking=True)
                             host[k] = buf
                         else:

@@ -2,7 +2,7 @@
 on four samples of 4096 tokens (16 query / 8 key-value heads of 128, bf16), HIP events, random order; every
 variant is first held to the default's results.
 
-    python tools/tune_attn_long.py build | run
+    python tools/tune_attn_long.py build | run  ["-DPRL_ATTN_...=.. -D..." ...]   (the same variants for both)
 """
 import ctypes, random, statistics, subprocess, sys
 from pathlib import Path
@@ -17,9 +17,9 @@ VARIANTS = {
     "pitch152": ["-DPRL_ATTN_PITCH=152"],
     "dkv_split2": ["-DPRL_ATTN_DKV_SPLIT=2"],
 }
-if len(sys.argv) > 2:
-    extra = sys.argv[2:]
-    VARIANTS = {"default": [], **{e.strip("-D").replace("=", "_"): [e] for e in extra}}
+if len(sys.argv) > 2:  # variants named on the command line: one argument each, its -D flags separated by spaces
+    VARIANTS = {"default": [], **{e.replace("-DPRL_ATTN_", "").replace("=", "").replace(" ", "_"): e.split()
+                                  for e in sys.argv[2:]}}
 
 
 def build():
