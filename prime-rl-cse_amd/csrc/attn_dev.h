@@ -114,6 +114,22 @@ __device__ __forceinline__ void sample_range(const int32_t* cu, int s, int64_t T
   len = (int)n;
 }
 
+// Which piece of work a workgroup of a 1-D grid takes.  Workgroups that read the same tiles (the query heads of a
+// group read the same K and V; the halves of a dK / dV tile read the same Q, dO, K and V; in the long-sample kernels
+// all query tiles of a group walk over the same K / V tiles) are dealt to ONE XCD, next to each other: the hardware
+// hands workgroup i to XCD i % 8, and every XCD has an L2 of its own, so what such workgroups share is read from
+// memory once and from that L2 afterwards.  XCD x takes the groups x, x + 8, ... one after the other, `per_group`
+// consecutive workgroups each.  False: padding (the grid is 8 * ceil(groups / 8) * per_group workgroups).
+__device__ __forceinline__ bool xcd_item(int per_group, int groups, int& group, int& within) {
+  const int id = (int)blockIdx.x, slot = id >> 3;
+  group = (id & 7) + 8 * (slot / per_group);
+  within = slot % per_group;
+  return group < groups;
+}
+static inline unsigned xcd_grid(int per_group, int groups) {
+  return 8u * (unsigned)((groups + 7) / 8) * (unsigned)per_group;
+}
+
 static inline bool attn_view_ok(const void* p, int64_t ts, int64_t hs) {
   return p && (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ts % 8 == 0 && hs % 8 == 0 && ts > 0 && hs > 0;
 }

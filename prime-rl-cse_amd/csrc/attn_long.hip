@@ -32,18 +32,6 @@ __device__ __forceinline__ void sample_span(const int32_t* cu, int s, int64_t T,
   len = (int)n;
 }
 
-// Which piece of work this workgroup takes.  The workgroups of one (sample, key/value head) group walk over the same
-// K / V tiles (forward, dQ: all query tiles of all query heads of the group) or the same Q / dO tiles (dK, dV: all key
-// tiles), so a group's workgroups are dealt to ONE XCD (the hardware hands workgroup i to XCD i % 8, and every XCD
-// has an L2 of its own): XCD x takes the groups x, x + 8, ... one after the other, `per_group` consecutive
-// workgroups each, and what a group shares is read from memory once and from that L2 afterwards.  False: padding.
-__device__ __forceinline__ bool xcd_item(int per_group, int groups, int& group, int& within) {
-  const int id = (int)blockIdx.x, slot = id >> 3;
-  group = (id & 7) + 8 * (slot / per_group);
-  within = slot % per_group;
-  return group < groups;
-}
-
 // rows row0 .. row0+127 of the sample, one head each, into N natural [token][d] images; rows at or past `len`
 // are zero.  Reads without a branch (see stage_images); needs len >= 1.
 template <int N>
@@ -484,8 +472,7 @@ extern "C" int prl_attn_long_fwd(const void* q, const int64_t* q_strides, const 
   const AttnView vv{static_cast<const uint16_t*>(v), v_strides[0], v_strides[1]};
   const int tiles = (int)((max_len + kAL - 1) / kAL), groups = n_samples * kv_heads, G = q_heads / kv_heads;
   PRL_REQUIRE((int64_t)((groups + 7) / 8) * tiles * q_heads < ((int64_t)1 << 28), "attn_long_fwd: too much work for one launch");
-  const unsigned grid = 8u * (unsigned)((groups + 7) / 8) * (unsigned)(tiles * G);
-  hipLaunchKernelGGL(k_attn_long_fwd, dim3(grid), dim3(kAThreads), kLongFwdLds, (hipStream_t)stream, qv, kv, vv,
+  hipLaunchKernelGGL(k_attn_long_fwd, dim3(xcd_grid(tiles * G, groups)), dim3(kAThreads), kLongFwdLds, (hipStream_t)stream, qv, kv, vv,
                      static_cast<uint16_t*>(out), out_strides[0], out_strides[1], lse2, cu_seqlens, q_heads, G, T,
                      scale * kLog2e, tiles, groups);
   PRL_CHECK_LAUNCH("attn_long_fwd");
@@ -520,12 +507,11 @@ extern "C" int prl_attn_long_bwd(const void* q, const int64_t* q_strides, const 
   const float c = scale * kLog2e;
   const int tiles = (int)((max_len + kAL - 1) / kAL), groups = n_samples * kv_heads;
   PRL_REQUIRE((int64_t)((groups + 7) / 8) * tiles * q_heads < ((int64_t)1 << 28), "attn_long_bwd: too much work for one launch");
-  const unsigned per_xcd = (unsigned)((groups + 7) / 8);
-  hipLaunchKernelGGL(k_attn_long_bwd_dq, dim3(8u * per_xcd * (unsigned)(tiles * G)), dim3(kAThreads), kLongDqLds,
+  hipLaunchKernelGGL(k_attn_long_bwd_dq, dim3(xcd_grid(tiles * G, groups)), dim3(kAThreads), kLongDqLds,
                      (hipStream_t)stream, qv, kv, vv, ov, dov, lse2, delta, static_cast<uint16_t*>(dq), dq_strides[0],
                      dq_strides[1], cu_seqlens, q_heads, G, T, c, scale, tiles, groups);
   PRL_CHECK_LAUNCH("attn_long_bwd (dq)");
-  hipLaunchKernelGGL(k_attn_long_bwd_dkv<PRL_ATTN_DKV_SPLIT>, dim3(8u * per_xcd * (unsigned)(tiles * PRL_ATTN_DKV_SPLIT)),
+  hipLaunchKernelGGL(k_attn_long_bwd_dkv<PRL_ATTN_DKV_SPLIT>, dim3(xcd_grid(tiles * PRL_ATTN_DKV_SPLIT, groups)),
                      dim3(kAThreads), kLongDkvLds, (hipStream_t)stream, qv, kv, vv, dov, lse2, delta,
                      static_cast<uint16_t*>(dk), dk_strides[0], dk_strides[1], static_cast<uint16_t*>(dv), dv_strides[0],
                      dv_strides[1], cu_seqlens, kv_heads, G, T, c, scale, tiles, groups);

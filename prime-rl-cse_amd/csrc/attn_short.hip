@@ -26,11 +26,14 @@ namespace prl {
 // lse2 is the base-2 log-sum-exp of the scaled scores, [head][token]
 __global__ __launch_bounds__(kAThreads) void k_attn_short_fwd(AttnView q, AttnView k, AttnView v, uint16_t* o,
                                                               int64_t o_ts, int64_t o_hs, float* lse2,
-                                                              const int32_t* cu, int Hq, int G, int64_t T, float c) {
+                                                              const int32_t* cu, int Hq, int G, int64_t T, float c,
+                                                              int groups) {
   extern __shared__ __align__(16) uint16_t lds[];
   uint16_t* Ks = lds;
   uint16_t* Vs = lds + kAImg;
-  const int s = blockIdx.x / Hq, hq = blockIdx.x % Hq, hkv = hq / G;
+  int group, within;  // group = (sample, key/value head); its G query heads share K and V
+  if (!xcd_item(G, groups, group, within)) return;
+  const int Hkv = Hq / G, s = group / Hkv, hkv = group % Hkv, hq = hkv * G + within;
   int64_t start;
   int len;
   sample_range(cu, s, T, start, len);
@@ -119,11 +122,13 @@ __global__ __launch_bounds__(kAThreads) void k_attn_short_bwd_dq(AttnView q, Att
                                                                  AttnView dout, const float* lse2, float* delta,
                                                                  uint16_t* dq, int64_t dq_ts, int64_t dq_hs,
                                                                  const int32_t* cu, int Hq, int G, int64_t T,
-                                                                 float c, float scale) {
+                                                                 float c, float scale, int groups) {
   extern __shared__ __align__(16) uint16_t lds[];
   uint16_t* Ks = lds;
   uint16_t* Vs = lds + kAImg;
-  const int s = blockIdx.x / Hq, hq = blockIdx.x % Hq, hkv = hq / G;
+  int group, within;
+  if (!xcd_item(G, groups, group, within)) return;
+  const int Hkv = Hq / G, s = group / Hkv, hkv = group % Hkv, hq = hkv * G + within;
   int64_t start;
   int len;
   sample_range(cu, s, T, start, len);
@@ -212,13 +217,14 @@ __global__ __launch_bounds__(kAThreads, 2) void k_attn_short_bwd_dkv(AttnView q,
                                                                      const float* delta, uint16_t* dk, int64_t dk_ts,
                                                                      int64_t dk_hs, uint16_t* dv, int64_t dv_ts,
                                                                      int64_t dv_hs, const int32_t* cu, int Hkv, int G,
-                                                                     int64_t T, float c, float scale) {
+                                                                     int64_t T, float c, float scale, int groups) {
   extern __shared__ __align__(16) uint16_t lds[];
   uint16_t* Qs = lds;
   uint16_t* Os = lds + kAImg;  // dO
   float* row_lse = reinterpret_cast<float*>(lds + 2 * kAImg);
   float* row_delta = row_lse + kAL;
-  const int dhalf = blockIdx.x & 1, pair = blockIdx.x >> 1;
+  int pair, dhalf;  // the two halves read the same Q, dO, K and V
+  if (!xcd_item(2, groups, pair, dhalf)) return;
   const int s = pair / Hkv, hkv = pair % Hkv;
   int64_t start;
   int len;
@@ -351,7 +357,7 @@ extern "C" int prl_attn_short_supported(int dtype, int64_t head_dim, int64_t max
   PRL_REQUIRE(scale > 0.0f, name ": the score scale must be positive");                                      \
   if (n_samples == 0 || T == 0) return PRL_OK;                                                                \
   PRL_REQUIRE(cu_seqlens, name ": the sample table must not be NULL");                                       \
-  PRL_REQUIRE((int64_t)n_samples * q_heads <= 0x7fffffffLL, name ": too many (sample, head) pairs")
+  PRL_REQUIRE((int64_t)(n_samples + 8) * q_heads <= 0x3fffffffLL, name ": too many (sample, head) pairs")
 
 extern "C" int prl_attn_short_fwd(const void* q, const int64_t* q_strides, const void* k, const int64_t* k_strides,
                                   const void* v, const int64_t* v_strides, void* out, const int64_t* out_strides,
@@ -367,9 +373,10 @@ extern "C" int prl_attn_short_fwd(const void* q, const int64_t* q_strides, const
   const AttnView qv{static_cast<const uint16_t*>(q), q_strides[0], q_strides[1]};
   const AttnView kv{static_cast<const uint16_t*>(k), k_strides[0], k_strides[1]};
   const AttnView vv{static_cast<const uint16_t*>(v), v_strides[0], v_strides[1]};
-  hipLaunchKernelGGL(k_attn_short_fwd, dim3((unsigned)(n_samples * q_heads)), dim3(kAThreads), kFwdLds,
+  const int groups = n_samples * kv_heads;
+  hipLaunchKernelGGL(k_attn_short_fwd, dim3(xcd_grid(q_heads / kv_heads, groups)), dim3(kAThreads), kFwdLds,
                      (hipStream_t)stream, qv, kv, vv, static_cast<uint16_t*>(out), out_strides[0], out_strides[1],
-                     lse2, cu_seqlens, q_heads, q_heads / kv_heads, T, scale * kLog2e);
+                     lse2, cu_seqlens, q_heads, q_heads / kv_heads, T, scale * kLog2e, groups);
   PRL_CHECK_LAUNCH("attn_short_fwd");
   return PRL_OK;
 }
@@ -399,14 +406,15 @@ extern "C" int prl_attn_short_bwd(const void* q, const int64_t* q_strides, const
   const AttnView dov{static_cast<const uint16_t*>(dout), dout_strides[0], dout_strides[1]};
   const int G = q_heads / kv_heads;
   const float c = scale * kLog2e;
-  hipLaunchKernelGGL(k_attn_short_bwd_dq, dim3((unsigned)(n_samples * q_heads)), dim3(kAThreads), kDqLds,
+  const int groups = n_samples * kv_heads;
+  hipLaunchKernelGGL(k_attn_short_bwd_dq, dim3(xcd_grid(G, groups)), dim3(kAThreads), kDqLds,
                      (hipStream_t)stream, qv, kv, vv, ov, dov, lse2, delta, static_cast<uint16_t*>(dq), dq_strides[0],
-                     dq_strides[1], cu_seqlens, q_heads, G, T, c, scale);
+                     dq_strides[1], cu_seqlens, q_heads, G, T, c, scale, groups);
   PRL_CHECK_LAUNCH("attn_short_bwd (dq)");
-  hipLaunchKernelGGL(k_attn_short_bwd_dkv, dim3((unsigned)(2 * n_samples * kv_heads)), dim3(kAThreads), kDkvLds,
+  hipLaunchKernelGGL(k_attn_short_bwd_dkv, dim3(xcd_grid(2, groups)), dim3(kAThreads), kDkvLds,
                      (hipStream_t)stream, qv, kv, vv, dov, lse2, delta, static_cast<uint16_t*>(dk), dk_strides[0],
                      dk_strides[1], static_cast<uint16_t*>(dv), dv_strides[0], dv_strides[1], cu_seqlens, kv_heads, G,
-                     T, c, scale);
+                     T, c, scale, groups);
   PRL_CHECK_LAUNCH("attn_short_bwd (dk, dv)");
   return PRL_OK;
 }
