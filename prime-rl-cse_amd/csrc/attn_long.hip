@@ -18,6 +18,8 @@
 // Workgroups with the most blocks to walk start first.
 #include "attn_dev.h"
 
+// build-time tunables (tools/tune_attn_long.py)
+
 namespace prl {
 
 // tokens [start, start + len) of sample s, clamped into the row
@@ -32,30 +34,183 @@ __device__ __forceinline__ void sample_span(const int32_t* cu, int s, int64_t T,
   len = (int)n;
 }
 
-// rows row0 .. row0+127 of the sample, one head each, into N natural [token][d] images; rows at or past `len`
+// Two LDS layouts of a [128 tokens][128 d] tile, both row-major in 16-byte slots (8 elements):
+//   kRows   pitch 136 elements (17 slots): for an image that is only read row-wise (ds_read_b128: its four 16-lane
+//           groups then hit 16 different slots);
+//   kBoth   pitch 160 elements (20 slots) with slot s of row t stored at slot s ^ ((t >> 2) & 3): for an image that
+//           is (also) read transposed.  A transposing read's 32-lane group takes 64 bytes from each of four
+//           consecutive rows; with 17 slots between rows those four pieces overlap on the banks (up to 4-way
+//           conflicts, measured as twice the conflict-free LDS time in these kernels), with 20 they lie side by side
+//           (4 x 16 banks), and the swizzle keeps the row-wise reads, whose 16-lane groups hold rows 4 apart,
+//           conflict-free as well.  The 64 bytes behind every row's data are free for other things.
+enum Layout { kRows = 0, kBoth = 1 };
+template <int L> struct Lay;
+template <> struct Lay<kRows> { static constexpr int pitch = 136; };
+template <> struct Lay<kBoth> { static constexpr int pitch = 160; };
+// Per-lane constants of the two kinds of read, worked out once per kernel so that every read is one base register
+// plus an immediate: the swizzle of a row depends on (row >> 2) & 3 only, which for the rows a lane touches is the
+// same in every 32-row block (row-wise reads: row = 32 mt + r) and in every 16-token step (transposing reads).
+struct RowLane {  // row-wise fragment of row 32 mt + r: element offset = 32 mt * pitch + base + 32 (kk >> 1) + (kk & 1 ? odd : even)
+  int base, even, odd;
+};
+template <int L>
+__device__ __forceinline__ RowLane row_lane(int r, int h) {
+  const int x = L == kBoth ? (r >> 2) & 3 : 0;
+  return {r * Lay<L>::pitch, 8 * (h ^ x), 8 * ((2 + h) ^ x)};
+}
+template <int L>
+__device__ __forceinline__ bf16x8 frag_rows_l(const uint16_t* img, const RowLane& t, int mt, int kk) {
+  return as_frag(*reinterpret_cast<const u32x4*>(img + 32 * mt * Lay<L>::pitch + t.base + 32 * (kk >> 1) +
+                                                 ((kk & 1) ? t.odd : t.even)));
+}
+struct TrLane {  // transposing fragment at tokens tok0 + 16 s, columns d0: offsets of the lane's two 8-byte pieces
+  int lo, hi;
+};
+__device__ __forceinline__ TrLane tr_lane(int lane) {
+  const int i = lane & 15, grp = lane >> 4, g1 = grp >> 1, q = i >> 2;
+  const int b = 2 * (grp & 1) + ((i & 3) >> 1), within = 4 * (i & 1);
+  constexpr int P = Lay<kBoth>::pitch;
+  return {(4 * g1 + q) * P + 8 * (b ^ g1) + within, (4 * g1 + q + 8) * P + 8 * (b ^ ((g1 + 2) & 3)) + within};
+}
+// (see frag_cols: the same fragment out of a kBoth image; tok0 a multiple of 32, d0 of 32)
+__device__ __forceinline__ bf16x8 frag_cols_l(const uint16_t* img, int d0, int tok0, int s, const TrLane& t) {
+  const uint16_t* p = img + (tok0 + 16 * s) * Lay<kBoth>::pitch + d0;
+  typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + t.lo));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + t.hi));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  return __builtin_bit_cast(bf16x8, v);
+}
+// where thread `tid` of the staging loops puts its 16 bytes of round `it`: token 16 it + tid / 16, slot tid % 16;
+// (token >> 2) & 3 is the thread's wave index in every round
+template <int L>
+__device__ __forceinline__ int stage_at(int it) {
+  const int t4 = threadIdx.x >> 4, ch = threadIdx.x & 15, x = L == kBoth ? (threadIdx.x >> 6) & 3 : 0;
+  return (16 * it + t4) * Lay<L>::pitch + 8 * (ch ^ x);
+}
+
+// rows row0 .. row0+127 of the sample, one head each, into two images of layouts L0 and L1; rows at or past `len`
 // are zero.  Reads without a branch (see stage_images); needs len >= 1.
-template <int N>
-__device__ __forceinline__ void stage_tile(uint16_t* const (&img)[N], const AttnView* const (&x)[N], int64_t start,
-                                           int len, int row0, const int (&head)[N]) {
+template <int L0, int L1>
+__device__ __forceinline__ void stage_pair(uint16_t* img0, uint16_t* img1, const AttnView& x0, const AttnView& x1,
+                                           int64_t start, int len, int row0, int head0, int head1) {
   constexpr int kIt = kAL * kAD / 8 / kAThreads;
-  u32x4 v[N][kIt];
+  u32x4 v[2][kIt];
 #pragma unroll
-  for (int n = 0; n < N; ++n) {
-#pragma unroll
-    for (int it = 0; it < kIt; ++it) {
-      const int id = it * kAThreads + threadIdx.x, tok = row0 + (id >> 4), ch = id & 15;
-      const int src = tok < len ? tok : len - 1;
-      v[n][it] = *reinterpret_cast<const u32x4*>(x[n]->p + (start + src) * x[n]->ts + head[n] * x[n]->hs + ch * 8);
-    }
+  for (int it = 0; it < kIt; ++it) {
+    const int id = it * kAThreads + threadIdx.x, tok = row0 + (id >> 4), ch = id & 15;
+    const int src = tok < len ? tok : len - 1;
+    v[0][it] = *reinterpret_cast<const u32x4*>(x0.p + (start + src) * x0.ts + head0 * x0.hs + ch * 8);
+    v[1][it] = *reinterpret_cast<const u32x4*>(x1.p + (start + src) * x1.ts + head1 * x1.hs + ch * 8);
   }
 #pragma unroll
-  for (int n = 0; n < N; ++n) {
+  for (int it = 0; it < kIt; ++it) {
+    const int tok = 16 * it + (threadIdx.x >> 4);
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    *reinterpret_cast<u32x4*>(img0 + stage_at<L0>(it)) = row0 + tok < len ? v[0][it] : zero;
+    *reinterpret_cast<u32x4*>(img1 + stage_at<L1>(it)) = row0 + tok < len ? v[1][it] : zero;
+  }
+}
+// one image
+template <int L0>
+__device__ __forceinline__ void stage_one(uint16_t* img0, const AttnView& x0, int64_t start, int len, int row0,
+                                          int head0) {
+  constexpr int kIt = kAL * kAD / 8 / kAThreads;
+  u32x4 v[kIt];
 #pragma unroll
-    for (int it = 0; it < kIt; ++it) {
-      const int id = it * kAThreads + threadIdx.x, tok = id >> 4, ch = id & 15;
-      const u32x4 zero = {0u, 0u, 0u, 0u};
-      *reinterpret_cast<u32x4*>(img[n] + tok * kAP + ch * 8) = row0 + tok < len ? v[n][it] : zero;
+  for (int it = 0; it < kIt; ++it) {
+    const int id = it * kAThreads + threadIdx.x, tok = row0 + (id >> 4), ch = id & 15;
+    const int src = tok < len ? tok : len - 1;
+    v[it] = *reinterpret_cast<const u32x4*>(x0.p + (start + src) * x0.ts + head0 * x0.hs + ch * 8);
+  }
+#pragma unroll
+  for (int it = 0; it < kIt; ++it) {
+    const int tok = 16 * it + (threadIdx.x >> 4);
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    *reinterpret_cast<u32x4*>(img0 + stage_at<L0>(it)) = row0 + tok < len ? v[it] : zero;
+  }
+}
+
+// No LDS read or MFMA may be moved across this point; everything else may.  The product loops below are
+// software-pipelined by hand with it: the fragments of step i + 1 are requested before the products of step i are
+// issued.  Left alone, the compiler reuses ONE fragment register under this register budget and so puts a whole
+// LDS round trip in front of every product.
+#define PRL_PIPE_FENCE() __builtin_amdgcn_sched_barrier(0x476)
+
+// One block of the forward walk: NMT 32-key blocks of the staged tile, from block mt0 on, against the wave's 32
+// queries: scores, running maximum and sum (on the lane), probabilities, and their product with V added into `ot`.
+// MASKED: the block lies on the diagonal or holds the sample's end.
+template <int NMT, bool MASKED>
+__device__ __forceinline__ void fwd_block(const uint16_t* Ks, const uint16_t* Vs, const bf16x8 (&qf)[8],
+                                          f32x16 (&ot)[4], float& m, float& l, int mt0, int k0, int query, int len,
+                                          float c, int h, const RowLane& kl, const TrLane& vl) {
+  f32x16 st[NMT];
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt) st[mt] = f32x16{};
+  {
+    bf16x8 kf[2][NMT];
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt) kf[0][mt] = frag_rows_l<kRows>(Ks, kl, mt0 + mt, 0);
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      if (kk < 7) {
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt) kf[(kk + 1) & 1][mt] = frag_rows_l<kRows>(Ks, kl, mt0 + mt, kk + 1);
+      }
+      PRL_PIPE_FENCE();
+#pragma unroll
+      for (int mt = 0; mt < NMT; ++mt) st[mt] = mfma(kf[kk & 1][mt], qf[kk], st[mt]);
     }
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (MASKED) {
+        const int key = k0 + 32 * (mt0 + mt) + acc_row(i, h);
+        st[mt][i] = (key <= query && key < len) ? st[mt][i] : -INFINITY;
+      }
+      mx = fmaxf(mx, st[mt][i]);
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
+  // finite: every block walked holds a key that is at or before the lane's query and inside the sample
+  const float m_new = fmaxf(m, mx);
+  if (__any(m_new > m)) {  // (wave-uniform) some query's maximum moved: bring sums and accumulators to the new one
+    const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c);  // 0 at the first block (m = -inf), 1 where nothing moved
+    l *= alpha;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) ot[dt][i] *= alpha;
+    }
+  }
+  const float mc = m_new * c;
+  m = m_new;
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float p = __builtin_amdgcn_exp2f(fmaf(st[mt][i], c, -mc));  // c > 0: a masked score stays -inf, p = 0
+      st[mt][i] = p;
+      l += p;
+    }
+  }
+  bf16x8 vf[2][4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) vf[0][dt] = frag_cols_l(Vs, 32 * dt, 32 * mt0, 0, vl);
+#pragma unroll
+  for (int j = 0; j < 2 * NMT; ++j) {  // step j: 16 keys of block mt0 + j / 2
+    if (j + 1 < 2 * NMT) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) vf[(j + 1) & 1][dt] = frag_cols_l(Vs, 32 * dt, 32 * (mt0 + (j + 1) / 2), (j + 1) & 1, vl);
+    }
+    PRL_PIPE_FENCE();
+    const bf16x8 pf = acc_frag(st[j >> 1], j & 1);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) ot[dt] = mfma(vf[j & 1][dt], pf, ot[dt]);
   }
 }
 
@@ -65,8 +220,8 @@ __global__ __launch_bounds__(kAThreads, 2) void k_attn_long_fwd(AttnView q, Attn
                                                              const int32_t* cu, int Hq, int G, int64_t T, float c,
                                                              int tiles, int groups) {
   extern __shared__ __align__(16) uint16_t lds[];
-  uint16_t* Ks = lds;
-  uint16_t* Vs = lds + kAImg;
+  uint16_t* Ks = lds;                             // read row-wise only
+  uint16_t* Vs = lds + kAL * Lay<kRows>::pitch;   // read transposed only
   int group, within;
   if (!xcd_item(tiles * G, groups, group, within)) return;
   const int Hkv = Hq / G, s = group / Hkv, hkv = group % Hkv, hq = hkv * G + within % G;
@@ -84,83 +239,23 @@ __global__ __launch_bounds__(kAThreads, 2) void k_attn_long_fwd(AttnView q, Attn
   for (int kk = 0; kk < 8; ++kk) qf[kk] = frag_global(q, start, len, hq, query, kk, h);
   float m = -INFINITY, l = 0.0f;  // running maximum (raw scores) and this lane half's share of the running sum
   f32x16 ot[4] = {};
-  uint16_t* const imgs[2] = {Ks, Vs};
-  const AttnView* const views[2] = {&k, &v};
-  const int heads[2] = {hkv, hkv};
+  const RowLane kl = row_lane<kRows>(r, h);
+  const TrLane vl = tr_lane(lane);
 #pragma unroll 1
   for (int kt = 0; kt <= qt; ++kt) {
     const int k0 = kt * kAL;
     __syncthreads();  // the previous tile's images are no longer read
-    stage_tile<2>(imgs, views, start, len, k0, heads);
+    stage_pair<kRows, kBoth>(Ks, Vs, k, v, start, len, k0, hkv, hkv);
     __syncthreads();
     if (!active) continue;
-    const bool diag = kt == qt;
-    int ntile = 4;  // 32-key blocks of this tile the wave needs: all of them below the diagonal (they end before q0 < len)
-    f32x16 st[4];
-    float mx = -INFINITY;
-    if (!diag) {
-      // four independent accumulation chains: the LDS reads of one step are in flight while the products of the
-      // step before run
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) st[mt] = f32x16{};
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) st[mt] = mfma(frag_rows(Ks, 32 * mt + r, kk, h), qf[kk], st[mt]);
-      }
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, st[mt][i]);
-      }
+    if (kt < qt) {  // below the diagonal: every key is before every query of the tile and inside the sample
+      fwd_block<2, false>(Ks, Vs, qf, ot, m, l, 0, k0, query, len, c, h, kl, vl);
+      fwd_block<2, false>(Ks, Vs, qf, ot, m, l, 2, k0, query, len, c, h, kl, vl);
     } else {
-      ntile = (len - k0 + 31) >> 5;  // blocks that hold keys at all ...
+      int ntile = (len - k0 + 31) >> 5;  // blocks that hold keys at all ...
       if (ntile > w + 1) ntile = w + 1;  // ... and, causal, none beyond the wave's own queries
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        if (mt < ntile) {
-          f32x16 acc = {};
-#pragma unroll
-          for (int kk = 0; kk < 8; ++kk) acc = mfma(frag_rows(Ks, 32 * mt + r, kk, h), qf[kk], acc);
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int key = k0 + 32 * mt + acc_row(i, h);
-            acc[i] = (key <= query && key < len) ? acc[i] : -INFINITY;
-            mx = fmaxf(mx, acc[i]);
-          }
-          st[mt] = acc;
-        }
-      }
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
-    const float m_new = fmaxf(m, mx);  // finite: key k0 of every tile walked is at or before every query of the tile
-    if (__any(m_new > m)) {  // (wave-uniform) some query's maximum moved: bring sums and accumulators to the new one
-      const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c);  // 0 at the first tile (m = -inf), 1 where nothing moved
-      l *= alpha;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) ot[dt][i] *= alpha;
-      }
-    }
-    const float mc = m_new * c;
-    m = m_new;
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      if (mt < ntile) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(st[mt][i], c, -mc));  // c > 0: a masked score stays -inf, p = 0
-          st[mt][i] = p;
-          l += p;
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const bf16x8 pf = acc_frag(st[mt], s2);
-#pragma unroll
-          for (int dt = 0; dt < 4; ++dt) ot[dt] = mfma(frag_cols(Vs, 32 * dt, 32 * mt, s2, lane), pf, ot[dt]);
-        }
-      }
+#pragma unroll 1
+      for (int mt = 0; mt < ntile; ++mt) fwd_block<1, true>(Ks, Vs, qf, ot, m, l, mt, k0, query, len, c, h, kl, vl);
     }
   }
   if (!active) return;
@@ -189,8 +284,8 @@ __global__ __launch_bounds__(kAThreads, 2) void k_attn_long_bwd_dq(AttnView q, A
                                                                 const int32_t* cu, int Hq, int G, int64_t T, float c,
                                                                 float scale, int tiles, int groups) {
   extern __shared__ __align__(16) uint16_t lds[];
-  uint16_t* Ks = lds;
-  uint16_t* Vs = lds + kAImg;
+  uint16_t* Ks = lds;                             // read row-wise (S) and transposed (dQ)
+  uint16_t* Vs = lds + kAL * Lay<kBoth>::pitch;   // read row-wise only
   int group, within;
   if (!xcd_item(tiles * G, groups, group, within)) return;
   const int Hkv = Hq / G, s = group / Hkv, hkv = group % Hkv, hq = hkv * G + within % G;
@@ -224,14 +319,13 @@ __global__ __launch_bounds__(kAThreads, 2) void k_attn_long_bwd_dq(AttnView q, A
   }
   const bool real = query < len;
   f32x16 dqt[4] = {};
-  uint16_t* const imgs[2] = {Ks, Vs};
-  const AttnView* const views[2] = {&k, &v};
-  const int heads[2] = {hkv, hkv};
+  const RowLane kl = row_lane<kBoth>(r, h), vl = row_lane<kRows>(r, h);
+  const TrLane tl = tr_lane(lane);
 #pragma unroll 1
   for (int kt = 0; kt <= qt; ++kt) {
     const int k0 = kt * kAL;
     __syncthreads();
-    stage_tile<2>(imgs, views, start, len, k0, heads);
+    stage_pair<kBoth, kRows>(Ks, Vs, k, v, start, len, k0, hkv, hkv);
     __syncthreads();
     if (!active) continue;
     const bool diag = kt == qt;
@@ -244,8 +338,8 @@ __global__ __launch_bounds__(kAThreads, 2) void k_attn_long_bwd_dq(AttnView q, A
         f32x16 sa = {}, dp = {};
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
-          sa = mfma(frag_rows(Ks, 32 * mt + r, kk, h), qf[kk], sa);
-          dp = mfma(frag_rows(Vs, 32 * mt + r, kk, h), dof[kk], dp);
+          sa = mfma(frag_rows_l<kBoth>(Ks, kl, mt, kk), qf[kk], sa);
+          dp = mfma(frag_rows_l<kRows>(Vs, vl, mt, kk), dof[kk], dp);
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -258,7 +352,7 @@ __global__ __launch_bounds__(kAThreads, 2) void k_attn_long_bwd_dq(AttnView q, A
         for (int s2 = 0; s2 < 2; ++s2) {
           const bf16x8 df = acc_frag(sa, s2);
 #pragma unroll
-          for (int dt = 0; dt < 4; ++dt) dqt[dt] = mfma(frag_cols(Ks, 32 * dt, 32 * mt, s2, lane), df, dqt[dt]);
+          for (int dt = 0; dt < 4; ++dt) dqt[dt] = mfma(frag_cols_l(Ks, 32 * dt, 32 * mt, s2, tl), df, dqt[dt]);
         }
       }
     }
@@ -299,10 +393,12 @@ __global__ __launch_bounds__(kAThreads, 2) void k_attn_long_bwd_dkv(AttnView q, 
                                                                     int groups) {
   constexpr int ND = 4 / DSPLIT;  // 32-wide blocks of the head dimension this workgroup owns
   extern __shared__ __align__(16) uint16_t lds[];
-  uint16_t* Qs = lds;
-  uint16_t* Os = lds + kAImg;  // dO
-  float* row_lse = reinterpret_cast<float*>(lds + 2 * kAImg);
-  float* row_delta = row_lse + kAL;
+  uint16_t* Qs = lds;                             // both read row-wise (S, dP) and transposed (dK, dV)
+  uint16_t* Os = lds + kAL * Lay<kBoth>::pitch;   // dO
+  // log-sum-exp and delta of the tile's 128 query rows live in the 64 bytes behind the data of the images' first
+  // eight rows (16 floats per row): value n at row n / 16, float n % 16
+  auto lse_at = [&](int n) { return reinterpret_cast<float*>(Qs + (n >> 4) * Lay<kBoth>::pitch + kAD) + (n & 15); };
+  auto delta_at = [&](int n) { return reinterpret_cast<float*>(Os + (n >> 4) * Lay<kBoth>::pitch + kAD) + (n & 15); };
   int group, within;
   if (!xcd_item(tiles * DSPLIT, groups, group, within)) return;
   const int dpart = within % DSPLIT, kt = within / DSPLIT;  // the first key tiles have the longest walk
@@ -323,6 +419,8 @@ __global__ __launch_bounds__(kAThreads, 2) void k_attn_long_bwd_dkv(AttnView q, 
   }
   const int nqt = (len + kAL - 1) / kAL;
   f32x16 dkt[ND] = {}, dvt[ND] = {};
+  const RowLane rl = row_lane<kBoth>(r, h);
+  const TrLane tl = tr_lane(lane);
 #pragma unroll 1
   for (int g = 0; g < G; ++g) {
     const int hq = hkv * G + g;
@@ -331,24 +429,15 @@ __global__ __launch_bounds__(kAThreads, 2) void k_attn_long_bwd_dkv(AttnView q, 
       const int q0 = qt * kAL;
       __syncthreads();  // the previous images are no longer read
 #if PRL_ATTN_DKV_ROUNDS == 1
-      {  // both images in one round of loads (64 registers in flight)
-        uint16_t* const imgs[2] = {Qs, Os};
-        const AttnView* const views[2] = {&q, &dout};
-        const int hs[2] = {hq, hq};
-        stage_tile<2>(imgs, views, start, len, q0, hs);
-      }
+      stage_pair<kBoth, kBoth>(Qs, Os, q, dout, start, len, q0, hq, hq);  // one round of loads, 64 registers in flight
 #else
-      for (int j = 0; j < 2; ++j) {  // one image per round of loads: registers are scarce here
-        uint16_t* const imgs[1] = {j ? Os : Qs};
-        const AttnView* const views[1] = {j ? &dout : &q};
-        const int hs[1] = {hq};
-        stage_tile<1>(imgs, views, start, len, q0, hs);
-      }
+      stage_one<kBoth>(Qs, q, start, len, q0, hq);  // one image per round of loads: registers are scarce here
+      stage_one<kBoth>(Os, dout, start, len, q0, hq);
 #endif
       if (threadIdx.x < kAL) {
         const bool in = q0 + (int)threadIdx.x < len;
-        row_lse[threadIdx.x] = in ? lse2[(int64_t)hq * T + start + q0 + threadIdx.x] : 0.0f;
-        row_delta[threadIdx.x] = in ? delta[(int64_t)hq * T + start + q0 + threadIdx.x] : 0.0f;
+        *lse_at(threadIdx.x) = in ? lse2[(int64_t)hq * T + start + q0 + threadIdx.x] : 0.0f;
+        *delta_at(threadIdx.x) = in ? delta[(int64_t)hq * T + start + q0 + threadIdx.x] : 0.0f;
       }
       __syncthreads();
       if (!active) continue;
@@ -362,8 +451,8 @@ __global__ __launch_bounds__(kAThreads, 2) void k_attn_long_bwd_dkv(AttnView q, 
           f32x16 sa = {}, dp = {};
 #pragma unroll
           for (int kk = 0; kk < 8; ++kk) {
-            sa = mfma(frag_rows(Qs, 32 * mt + r, kk, h), kf[kk], sa);  // S: rows = queries, lane = key
-            dp = mfma(frag_rows(Os, 32 * mt + r, kk, h), vf[kk], dp);  // dP = dO V^T
+            sa = mfma(frag_rows_l<kBoth>(Qs, rl, mt, kk), kf[kk], sa);  // S: rows = queries, lane = key
+            dp = mfma(frag_rows_l<kBoth>(Os, rl, mt, kk), vf[kk], dp);  // dP = dO V^T
           }
           // log-sum-exp and delta of the 16 query rows this lane half holds (rows 8j + 4h .. + 3, j = 0 .. 3): four
           // 16-byte reads each, and no branch around them.  Rows past the sample's end need no mask: their Q and dO
@@ -371,8 +460,8 @@ __global__ __launch_bounds__(kAThreads, 2) void k_attn_long_bwd_dkv(AttnView q, 
           f32x4 lse_r[4], del_r[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            lse_r[j] = *reinterpret_cast<const f32x4*>(row_lse + 32 * mt + 8 * j + 4 * h);
-            del_r[j] = *reinterpret_cast<const f32x4*>(row_delta + 32 * mt + 8 * j + 4 * h);
+            lse_r[j] = *reinterpret_cast<const f32x4*>(lse_at(32 * mt + 8 * j + 4 * h));
+            del_r[j] = *reinterpret_cast<const f32x4*>(delta_at(32 * mt + 8 * j + 4 * h));
           }
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
@@ -387,8 +476,8 @@ __global__ __launch_bounds__(kAThreads, 2) void k_attn_long_bwd_dkv(AttnView q, 
 #pragma unroll
             for (int dt = 0; dt < ND; ++dt) {
               const int d0 = 32 * (ND * dpart + dt);
-              dvt[dt] = mfma(frag_cols(Os, d0, 32 * mt, s2, lane), pf, dvt[dt]);  // dV^T += dO^T P
-              dkt[dt] = mfma(frag_cols(Qs, d0, 32 * mt, s2, lane), df, dkt[dt]);  // dK^T += Q^T dS
+              dvt[dt] = mfma(frag_cols_l(Os, d0, 32 * mt, s2, tl), pf, dvt[dt]);  // dV^T += dO^T P
+              dkt[dt] = mfma(frag_cols_l(Qs, d0, 32 * mt, s2, tl), df, dkt[dt]);  // dK^T += Q^T dS
             }
           }
         }
@@ -414,9 +503,9 @@ __global__ __launch_bounds__(kAThreads, 2) void k_attn_long_bwd_dkv(AttnView q, 
   }
 }
 
-constexpr size_t kLongFwdLds = 2 * kAImg * sizeof(uint16_t);
-constexpr size_t kLongDqLds = 2 * kAImg * sizeof(uint16_t);
-constexpr size_t kLongDkvLds = 2 * kAImg * sizeof(uint16_t) + 2 * kAL * sizeof(float);
+constexpr size_t kLongFwdLds = kAL * (Lay<kRows>::pitch + Lay<kBoth>::pitch) * sizeof(uint16_t);
+constexpr size_t kLongDqLds = kAL * (Lay<kRows>::pitch + Lay<kBoth>::pitch) * sizeof(uint16_t);
+constexpr size_t kLongDkvLds = 2 * kAL * Lay<kBoth>::pitch * sizeof(uint16_t);  // 80 KB: two workgroups fill the LDS exactly
 
 // The kernels use more than the 64 KB of LDS a launch gets by default; raised once per thread and device.
 static int raise_long_lds_limits() {
