@@ -363,7 +363,8 @@ int prl_accumulate_first(const void* const* src, int src_dtype, const int64_t* d
  * Every tensor is [token][head][128] with the last dimension contiguous; `*_strides` = {token stride, head
  * stride} in elements (HOST arrays).  `cu_seqlens` (DEVICE, int32 [n_samples + 1]) holds the first token of
  * every sample and T at the end.  `lse2` (fp32 [q_heads][T]) receives the base-2 log-sum-exp of the scaled
- * scores; the backward reads it, needs `delta` (fp32 [q_heads][T]) as scratch, and writes dq, dk, dv (tokens
+ * scores; the backward reads it, needs `delta` (fp32 [q_heads][T]) as scratch (its contents afterwards are
+ * unspecified), and writes dq, dk, dv (tokens
  * outside every sample are left untouched).  Samples longer than 128 tokens are the caller's to exclude
  * (prl_attn_short_supported); a table that breaks the rule is clamped, never followed out of bounds.
  */

@@ -51,6 +51,11 @@ CASES = [
     ([40, 90, 3, 77], 8, 2, "fused"),
     ([128], 2, 1, "projection"),
     ([7], 4, 2, "head_major"),
+    # 128 (sample, key/value head) groups or more: the backward is the one kernel per group
+    ([1, 31, 32, 33, 128, 100, 64, 2, 97, 65, 127, 96, 5, 128, 77, 40, 12, 63], 16, 8, "fused"),
+    ([128, 3] * 16 + [50], 8, 4, "projection"),
+    ([17, 128, 64, 99] * 8, 16, 4, "head_major"),  # four query heads per key/value head
+    ([128, 1, 45, 80] * 4, 8, 8, "projection"),  # one
 ]
 
 
