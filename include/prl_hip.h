@@ -298,6 +298,20 @@ int prl_rmsnorm_bwd(const void* x, int64_t x_row_stride, const void* w, const fl
                     int64_t gy_row_stride, void* gx, int64_t gx_row_stride, void* gw, int dtype, int64_t rows,
                     int64_t H, void* workspace, size_t workspace_bytes, int64_t x_group, int64_t x_group_stride,
                     void* stream);
+/* The residual connection folded into the normalisation that follows it, as a transformer block has it twice
+ * (`hidden = residual + branch; normed = norm(hidden)`, the decoder layer of the blocks loaded at
+ * src/prime_rl/trainer/model.py:71-88): sum = cast(x + res) is written out (the next residual) and normalised in
+ * the same pass; the backward adds `gadd`, the gradient that reaches `sum` past the normalisation, to the rounded
+ * gx.  Results are those of a separate addition kernel before / after prl_rmsnorm_fwd / _bwd, bit for bit; what is
+ * saved is one read of the sum forward and one write and one read of gx backward.  Plain rows only (no groups);
+ * the workspace is prl_rmsnorm_bwd_workspace_bytes as above; x here is the stored sum. */
+int prl_add_rmsnorm_fwd(const void* x, int64_t x_row_stride, const void* res, int64_t res_row_stride, void* sum,
+                        int64_t sum_row_stride, const void* w, void* y, int64_t y_row_stride, float* rstd, int dtype,
+                        int64_t rows, int64_t H, float eps, void* stream);
+int prl_add_rmsnorm_bwd(const void* x, int64_t x_row_stride, const void* w, const float* rstd, const void* gy,
+                        int64_t gy_row_stride, const void* gadd, int64_t gadd_row_stride, void* gx,
+                        int64_t gx_row_stride, void* gw, int dtype, int64_t rows, int64_t H, void* workspace,
+                        size_t workspace_bytes, void* stream);
 
 /*
  * Rotary position embedding of query and key in one launch:

@@ -163,6 +163,16 @@ SIGNATURES = {
         [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int64,
          c_int64, c_void_p, c_size_t, c_int64, c_int64, c_void_p],
     ),
+    "prl_add_rmsnorm_fwd": (
+        c_int,
+        [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int,
+         c_int64, c_int64, c_float, c_void_p],
+    ),
+    "prl_add_rmsnorm_bwd": (
+        c_int,
+        [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
+         c_int, c_int64, c_int64, c_void_p, c_size_t, c_void_p],
+    ),
     "prl_graph_node_counts": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64)]),
     "prl_group_advantage": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "prl_stats_workspace_bytes": (c_size_t, [c_int]),

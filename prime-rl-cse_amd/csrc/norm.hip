@@ -19,6 +19,9 @@ constexpr int kNormThreads = 256;
 #define PRL_NORM_MAX_BLOCKS 256  // backward: also the number of partial rows the weight-gradient finish adds up
 #endif
 constexpr int kNormMaxBlocks = PRL_NORM_MAX_BLOCKS;
+#ifndef PRL_NORM_BWD_ROWS
+#define PRL_NORM_BWD_ROWS 1  // rows a row slot of the backward keeps in flight (tools/tune_norm_rows.py: 2 or 4 are no faster at H = 1024 and a quarter slower at 2048)
+#endif
 constexpr int kNormFwdMaxBlocks = 1024;  // forward: no partial sums, more workgroups only help (tools/tune_norm.py)
 
 template <int LPR>
@@ -53,7 +56,9 @@ __global__ __launch_bounds__(kNormThreads) void k_rmsnorm_fwd(const char* __rest
                                                               const char* __restrict__ w, char* __restrict__ y,
                                                               int64_t y_stride, float* __restrict__ rstd,
                                                               int64_t rows, int H, float eps, int64_t x_group,
-                                                              int64_t x_group_stride) {
+                                                              int64_t x_group_stride, const char* __restrict__ res,
+                                                              int64_t res_stride, char* __restrict__ sum,
+                                                              int64_t sum_stride) {
   constexpr int VE = DT == PRL_F32 ? 4 : 8;
   constexpr int RPB = kNormThreads / LPR;  // rows per workgroup and step
   const int li = threadIdx.x % LPR, slot = threadIdx.x / LPR;
@@ -73,6 +78,13 @@ __global__ __launch_bounds__(kNormThreads) void k_rmsnorm_fwd(const char* __rest
       const int v = li + k * LPR;
       if (v < nvec) {
         load_vec<DT>(xp, v, xv[k]);
+        if (res) {  // the row normalised is x + res, rounded to the storage type as a separate addition would
+          float rv[VE];
+          load_vec<DT>(res + row * res_stride, v, rv);
+#pragma unroll
+          for (int i = 0; i < VE; ++i) xv[k][i] = round_to(xv[k][i] + rv[i], DT);
+          store_unit<DT, VE>(sum + row * sum_stride, v, xv[k]);
+        }
 #pragma unroll
         for (int i = 0; i < VE; ++i) ss = fmaf(xv[k][i], xv[k][i], ss);
       }
@@ -94,13 +106,18 @@ __global__ __launch_bounds__(kNormThreads) void k_rmsnorm_fwd(const char* __rest
   }
 }
 
-// gx = rstd * (gy w - xh * mean(gy w xh)),  xh = x * rstd;  per-workgroup column sums of gy * cast(xh)
-// go to gw_part[blockIdx.x, :].
-template <int DT, int LPR, int NV>
+// gx = rstd * (gy w - xh * mean(gy w xh)) [+ gadd],  xh = x * rstd;  per-workgroup column sums of gy * cast(xh)
+// go to gw_part[blockIdx.x, :].  A row slot keeps RU rows in flight (all their loads issued before the first
+// is used); measured, one row is as fast as two or four: without the column-sum finish the kernel moves
+// 100 MB in ~20 us already.  `gadd`, when given, is a gradient that reaches
+// x along another path (the residual connection around the normalised branch): the result is what a separate
+// addition of the rounded gx would give.
+template <int DT, int LPR, int NV, int RU>
 __global__ __launch_bounds__(kNormThreads) void k_rmsnorm_bwd(const char* __restrict__ x, int64_t x_stride,
                                                               const char* __restrict__ w,
                                                               const float* __restrict__ rstd,
                                                               const char* __restrict__ gy, int64_t gy_stride,
+                                                              const char* __restrict__ gadd, int64_t gadd_stride,
                                                               char* __restrict__ gx, int64_t gx_stride,
                                                               float* __restrict__ gw_part, int64_t rows, int H,
                                                               int64_t x_group, int64_t x_group_stride) {
@@ -118,38 +135,70 @@ __global__ __launch_bounds__(kNormThreads) void k_rmsnorm_bwd(const char* __rest
 #pragma unroll
     for (int i = 0; i < VE; ++i) acc[k][i] = 0.0f;
   }
-  for (int64_t row = (int64_t)blockIdx.x * RPB + slot; row < rows; row += (int64_t)gridDim.x * RPB) {
-    const char* xp = x_row(x, row, x_stride, x_group, x_group_stride);
-    const char* gp = gy + row * gy_stride;
-    const float rs = rstd[row];
-    float xh[NV][VE], gw_[NV][VE];
-    float dot = 0.0f;
+  const int64_t step = (int64_t)gridDim.x * RPB;
+  for (int64_t row0 = (int64_t)blockIdx.x * RPB + slot; row0 < rows; row0 += step * RU) {
+    u32x4 rx[RU][NV], rg[RU][NV], ra[RU][NV];
+    float rs[RU];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      const int v = li + k * LPR;
-      if (v < nvec) {
-        float g[VE];
-        load_vec<DT>(xp, v, xh[k]);
-        load_vec<DT>(gp, v, g);
+    for (int u = 0; u < RU; ++u) {
+      const int64_t row = row0 + u * step < rows ? row0 + u * step : row0;  // past the end: row0 again, unused
+      const char* xp = x_row(x, row, x_stride, x_group, x_group_stride);
+      const char* gp = gy + row * gy_stride;
+      rs[u] = rstd[row];
 #pragma unroll
-        for (int i = 0; i < VE; ++i) {
-          xh[k][i] *= rs;
-          acc[k][i] = fmaf(g[i], round_to(xh[k][i], DT), acc[k][i]);
-          gw_[k][i] = g[i] * wv[k][i];
-          dot = fmaf(gw_[k][i], xh[k][i], dot);
+      for (int k = 0; k < NV; ++k) {
+        const int v = li + k * LPR;
+        if (v < nvec) {
+          rx[u][k] = reinterpret_cast<const u32x4*>(xp)[v];
+          rg[u][k] = reinterpret_cast<const u32x4*>(gp)[v];
+          if (gadd) ra[u][k] = reinterpret_cast<const u32x4*>(gadd + row * gadd_stride)[v];
         }
       }
     }
-    dot = row_sum<LPR>(dot) * inv_h;
-    char* op = gx + row * gx_stride;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      const int v = li + k * LPR;
-      if (v < nvec) {
-        float o[VE];
+    for (int u = 0; u < RU; ++u) {
+      const int64_t row = row0 + u * step;
+      if (row < rows) {
+        float xh[NV][VE], gw_[NV][VE];
+        float dot = 0.0f;
 #pragma unroll
-        for (int i = 0; i < VE; ++i) o[i] = rs * (gw_[k][i] - xh[k][i] * dot);
-        store_unit<DT, VE>(op, v, o);
+        for (int k = 0; k < NV; ++k) {
+          const int v = li + k * LPR;
+          if (v < nvec) {
+            float g[VE];
+            decode16_raw<DT>(rx[u][k], xh[k]);
+            decode16_raw<DT>(rg[u][k], g);
+#pragma unroll
+            for (int i = 0; i < VE; ++i) {
+              xh[k][i] *= rs[u];
+              acc[k][i] = fmaf(g[i], round_to(xh[k][i], DT), acc[k][i]);
+              gw_[k][i] = g[i] * wv[k][i];
+              dot = fmaf(gw_[k][i], xh[k][i], dot);
+            }
+          }
+        }
+        dot = row_sum<LPR>(dot) * inv_h;
+        char* op = gx + row * gx_stride;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+          const int v = li + k * LPR;
+          if (v < nvec) {
+            float o[VE];
+#pragma unroll
+            for (int i = 0; i < VE; ++i) o[i] = rs[u] * (gw_[k][i] - xh[k][i] * dot);
+            if (gadd) {
+              float av[VE];
+              decode16_raw<DT>(ra[u][k], av);
+#pragma unroll
+              for (int i = 0; i < VE; ++i) {
+                float r = round_to(o[i], DT);
+                if (DT == PRL_F32) asm volatile("" : "+v"(r));  // a value of its own: the addition is not fused into the product
+                o[i] = r + av[i];
+              }
+            }
+            store_unit<DT, VE>(op, v, o);
+          }
+        }
       }
     }
   }
@@ -270,26 +319,92 @@ static int norm_group_check(const char* who, int dtype, int64_t H, int64_t x_row
   return PRL_OK;
 }
 
-extern "C" int prl_rmsnorm_fwd(const void* x, int64_t x_row_stride, const void* w, void* y, int64_t y_row_stride,
-                               float* rstd, int dtype, int64_t rows, int64_t H, float eps, int64_t x_group,
-                               int64_t x_group_stride, void* stream) {
-  clear_error();
-  int rc = norm_check("rmsnorm_fwd", dtype, rows, H, x, w, y, x_row_stride, y_row_stride);
+static int rmsnorm_fwd_impl(const char* who, const void* x, int64_t x_row_stride, const void* res,
+                            int64_t res_row_stride, void* sum, int64_t sum_row_stride, const void* w, void* y,
+                            int64_t y_row_stride, float* rstd, int dtype, int64_t rows, int64_t H, float eps,
+                            int64_t x_group, int64_t x_group_stride, void* stream) {
+  int rc = norm_check(who, dtype, rows, H, x, w, y, x_row_stride, y_row_stride);
   if (rc != PRL_OK) return rc;
-  rc = norm_group_check("rmsnorm_fwd", dtype, H, x_row_stride, x_group, x_group_stride);
+  rc = norm_group_check(who, dtype, H, x_row_stride, x_group, x_group_stride);
   if (rc != PRL_OK) return rc;
+  if (res) {
+    rc = norm_check(who, dtype, rows, H, res, sum, sum, res_row_stride, sum_row_stride);
+    if (rc != PRL_OK) return rc;
+  }
   if (rows == 0) return PRL_OK;
-  PRL_REQUIRE(x && w && y, "rmsnorm_fwd: x, w and y must not be NULL");
+  PRL_REQUIRE(x && w && y, "%s: x, w and y must not be NULL", who);
   const int es = dtype == PRL_F32 ? 4 : 2, ve = 16 / es;
   const int lpr = norm_lpr(H, ve), nv = norm_nv(H, ve, lpr);
   const dim3 grid((unsigned)norm_blocks(rows, lpr, kNormFwdMaxBlocks)), block(kNormThreads);
   hipStream_t st = (hipStream_t)stream;
 #define PRL_FWD(DT, L, N, ...)                                                                                     \
   hipLaunchKernelGGL((k_rmsnorm_fwd<DT, L, N>), grid, block, 0, st, (const char*)x, x_row_stride * es, (const char*)w, \
-                     (char*)y, y_row_stride * es, rstd, rows, (int)H, eps, x_group, x_group_stride * es)
+                     (char*)y, y_row_stride * es, rstd, rows, (int)H, eps, x_group, x_group_stride * es,          \
+                     (const char*)res, res_row_stride * es, (char*)sum, sum_row_stride * es)
   PRL_NORM_DISPATCH(PRL_FWD, 0);
 #undef PRL_FWD
-  PRL_CHECK_LAUNCH("rmsnorm_fwd");
+  PRL_CHECK_LAUNCH(who);
+  return PRL_OK;
+}
+
+extern "C" int prl_rmsnorm_fwd(const void* x, int64_t x_row_stride, const void* w, void* y, int64_t y_row_stride,
+                               float* rstd, int dtype, int64_t rows, int64_t H, float eps, int64_t x_group,
+                               int64_t x_group_stride, void* stream) {
+  clear_error();
+  return rmsnorm_fwd_impl("rmsnorm_fwd", x, x_row_stride, nullptr, 0, nullptr, 0, w, y, y_row_stride, rstd, dtype, rows,
+                          H, eps, x_group, x_group_stride, stream);
+}
+
+extern "C" int prl_add_rmsnorm_fwd(const void* x, int64_t x_row_stride, const void* res, int64_t res_row_stride,
+                                   void* sum, int64_t sum_row_stride, const void* w, void* y, int64_t y_row_stride,
+                                   float* rstd, int dtype, int64_t rows, int64_t H, float eps, void* stream) {
+  clear_error();
+  PRL_REQUIRE(rows == 0 || (res && sum), "add_rmsnorm_fwd: res and sum must not be NULL");
+  return rmsnorm_fwd_impl("add_rmsnorm_fwd", x, x_row_stride, res, res_row_stride, sum, sum_row_stride, w, y,
+                          y_row_stride, rstd, dtype, rows, H, eps, 0, 0, stream);
+}
+
+static int rmsnorm_bwd_impl(const char* who, const void* x, int64_t x_row_stride, const void* w, const float* rstd,
+                            const void* gy, int64_t gy_row_stride, const void* gadd, int64_t gadd_row_stride, void* gx,
+                            int64_t gx_row_stride, void* gw, int dtype, int64_t rows, int64_t H, void* workspace,
+                            size_t workspace_bytes, int64_t x_group, int64_t x_group_stride, void* stream) {
+  int rc = norm_check(who, dtype, rows, H, x, gy, gx, x_row_stride, gy_row_stride);
+  if (rc != PRL_OK) return rc;
+  rc = norm_group_check(who, dtype, H, x_row_stride, x_group, x_group_stride);
+  if (rc != PRL_OK) return rc;
+  if (gadd) {
+    rc = norm_check(who, dtype, rows, H, gadd, gadd, gadd, gadd_row_stride, gadd_row_stride);
+    if (rc != PRL_OK) return rc;
+  }
+  PRL_REQUIRE(gx_row_stride >= H && ((gx_row_stride * (dtype == PRL_F32 ? 4 : 2)) & 15) == 0,
+              "%s: gx row stride must be >= H and 16-byte aligned", who);
+  PRL_REQUIRE(x && w && rstd && gy && gx && gw, "%s: x, w, rstd, gy, gx and gw must not be NULL", who);
+  PRL_REQUIRE((reinterpret_cast<uintptr_t>(w) & 15) == 0, "%s: w must be 16-byte aligned", who);
+  const int es = dtype == PRL_F32 ? 4 : 2, ve = 16 / es;
+  const int lpr = norm_lpr(H, ve), nv = norm_nv(H, ve, lpr);
+  const int nblk = norm_bwd_blocks(rows, lpr);
+  PRL_REQUIRE(workspace && workspace_bytes >= (size_t)nblk * H * sizeof(float),
+              "%s: workspace of %zu bytes needed (prl_rmsnorm_bwd_workspace_bytes)", who,
+              (size_t)nblk * H * sizeof(float));
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  const dim3 grid((unsigned)nblk), block(kNormThreads);
+  const size_t lds = (size_t)(kNormThreads / lpr) * H * sizeof(float);
+  // two rows in flight per row slot while their raw vectors fit the registers (rows of up to 4 vectors per lane)
+#define PRL_BWD(DT, L, N, ...)                                                                                      \
+  hipLaunchKernelGGL((k_rmsnorm_bwd<DT, L, N, (N <= 4 ? PRL_NORM_BWD_ROWS : 1)>), grid, block, lds, st, (const char*)x, \
+                     x_row_stride * es, (const char*)w, rstd, (const char*)gy, gy_row_stride * es, (const char*)gadd, \
+                     gadd_row_stride * es, (char*)gx, gx_row_stride * es, part, rows, (int)H, x_group,             \
+                     x_group_stride * es)
+  PRL_NORM_DISPATCH(PRL_BWD, 0);
+#undef PRL_BWD
+  PRL_CHECK_LAUNCH(who);
+  const dim3 fgrid((unsigned)((H + 31) / 32));
+  if (dtype == PRL_BF16)
+    hipLaunchKernelGGL((k_colsum_finish<PRL_BF16>), fgrid, dim3(1024), 0, st, part, nblk, (int)H, (char*)gw);
+  else
+    hipLaunchKernelGGL((k_colsum_finish<PRL_F32>), fgrid, dim3(1024), 0, st, part, nblk, (int)H, (char*)gw);
+  PRL_CHECK_LAUNCH(who);
   return PRL_OK;
 }
 
@@ -298,38 +413,18 @@ extern "C" int prl_rmsnorm_bwd(const void* x, int64_t x_row_stride, const void* 
                                int64_t rows, int64_t H, void* workspace, size_t workspace_bytes, int64_t x_group,
                                int64_t x_group_stride, void* stream) {
   clear_error();
-  int rc = norm_check("rmsnorm_bwd", dtype, rows, H, x, gy, gx, x_row_stride, gy_row_stride);
-  if (rc != PRL_OK) return rc;
-  rc = norm_group_check("rmsnorm_bwd", dtype, H, x_row_stride, x_group, x_group_stride);
-  if (rc != PRL_OK) return rc;
-  PRL_REQUIRE(gx_row_stride >= H && ((gx_row_stride * (dtype == PRL_F32 ? 4 : 2)) & 15) == 0,
-              "rmsnorm_bwd: gx row stride must be >= H and 16-byte aligned");
-  PRL_REQUIRE(x && w && rstd && gy && gx && gw, "rmsnorm_bwd: x, w, rstd, gy, gx and gw must not be NULL");
-  PRL_REQUIRE((reinterpret_cast<uintptr_t>(w) & 15) == 0, "rmsnorm_bwd: w must be 16-byte aligned");
-  const int es = dtype == PRL_F32 ? 4 : 2, ve = 16 / es;
-  const int lpr = norm_lpr(H, ve), nv = norm_nv(H, ve, lpr);
-  const int nblk = norm_bwd_blocks(rows, lpr);
-  PRL_REQUIRE(workspace && workspace_bytes >= (size_t)nblk * H * sizeof(float),
-              "rmsnorm_bwd: workspace of %zu bytes needed (prl_rmsnorm_bwd_workspace_bytes)",
-              (size_t)nblk * H * sizeof(float));
-  hipStream_t st = (hipStream_t)stream;
-  float* part = (float*)workspace;
-  const dim3 grid((unsigned)nblk), block(kNormThreads);
-  const size_t lds = (size_t)(kNormThreads / lpr) * H * sizeof(float);
-#define PRL_BWD(DT, L, N, ...)                                                                                      \
-  hipLaunchKernelGGL((k_rmsnorm_bwd<DT, L, N>), grid, block, lds, st, (const char*)x, x_row_stride * es, (const char*)w, \
-                     rstd, (const char*)gy, gy_row_stride * es, (char*)gx, gx_row_stride * es, part, rows, (int)H, \
-                     x_group, x_group_stride * es)
-  PRL_NORM_DISPATCH(PRL_BWD, 0);
-#undef PRL_BWD
-  PRL_CHECK_LAUNCH("rmsnorm_bwd");
-  const dim3 fgrid((unsigned)((H + 31) / 32));
-  if (dtype == PRL_BF16)
-    hipLaunchKernelGGL((k_colsum_finish<PRL_BF16>), fgrid, dim3(1024), 0, st, part, nblk, (int)H, (char*)gw);
-  else
-    hipLaunchKernelGGL((k_colsum_finish<PRL_F32>), fgrid, dim3(1024), 0, st, part, nblk, (int)H, (char*)gw);
-  PRL_CHECK_LAUNCH("rmsnorm_bwd(finish)");
-  return PRL_OK;
+  return rmsnorm_bwd_impl("rmsnorm_bwd", x, x_row_stride, w, rstd, gy, gy_row_stride, nullptr, 0, gx, gx_row_stride, gw,
+                          dtype, rows, H, workspace, workspace_bytes, x_group, x_group_stride, stream);
+}
+
+extern "C" int prl_add_rmsnorm_bwd(const void* x, int64_t x_row_stride, const void* w, const float* rstd,
+                                   const void* gy, int64_t gy_row_stride, const void* gadd, int64_t gadd_row_stride,
+                                   void* gx, int64_t gx_row_stride, void* gw, int dtype, int64_t rows, int64_t H,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  clear_error();
+  PRL_REQUIRE(gadd, "add_rmsnorm_bwd: gadd must not be NULL");
+  return rmsnorm_bwd_impl("add_rmsnorm_bwd", x, x_row_stride, w, rstd, gy, gy_row_stride, gadd, gadd_row_stride, gx,
+                          gx_row_stride, gw, dtype, rows, H, workspace, workspace_bytes, 0, 0, stream);
 }
 
 // ---------------------------------------------------------------- rotary position embedding

@@ -121,6 +121,80 @@ def rms_norm(x: Tensor, weight: Tensor, eps: float) -> Tensor:
     return _RMSNorm.apply(x, weight, float(eps))
 
 
+class _AddRMSNorm(torch.autograd.Function):
+    """(x + branch, norm(x + branch)) in one launch; the backward adds the gradient of the sum's other uses to the
+    normalisation's in its one launch.  Both as the separate kernels would round them."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, branch: Tensor, weight: Tensor, eps: float):
+        dev = C.require_device(x, branch, weight)
+        lib = C.load()
+        h = x.shape[-1]
+        rows = x.numel() // h
+        x2, b2 = x.reshape(rows, h), branch.reshape(rows, h)
+        w = weight.contiguous()
+        total = torch.empty((rows, h), dtype=x.dtype, device=dev)
+        y = torch.empty((rows, h), dtype=x.dtype, device=dev)
+        rstd = torch.empty(rows, dtype=torch.float32, device=dev)
+        with C.on_device(dev), C.timed("prl_add_rmsnorm_fwd", dev):
+            C.check(lib.prl_add_rmsnorm_fwd(C.ptr(x2), x2.stride(0) if rows > 1 else h, C.ptr(b2),
+                                            b2.stride(0) if rows > 1 else h, C.ptr(total), h, C.ptr(w), C.ptr(y), h,
+                                            C.ptr(rstd), C.dtype_code(x), rows, h, eps, C.stream_ptr(dev)),
+                    "prl_add_rmsnorm_fwd")
+        ctx.save_for_backward(total, w, rstd)
+        ctx.shape = x.shape
+        ctx.set_materialize_grads(False)  # an output nobody used arrives as None, not as a tensor of zeros
+        return total.view(x.shape), y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, gtotal: Tensor | None, gy: Tensor | None):
+        total, w, rstd = ctx.saved_tensors
+        dev = total.device
+        lib = C.load()
+        rows, h = total.shape
+        if gy is None:  # the normalised output went nowhere: only the other uses of the sum have a gradient
+            return gtotal, gtotal, None, None
+
+        def rows16(g: Tensor) -> Tensor:
+            g = g.reshape(rows, h)
+            if g.stride(-1) != 1 or (rows > 1 and (g.stride(0) * g.element_size()) % 16) or g.data_ptr() % 16:
+                g = g.contiguous()
+            return g
+
+        g2 = rows16(gy)
+        gx = torch.empty((rows, h), dtype=total.dtype, device=dev)
+        gw = torch.empty(h, dtype=w.dtype, device=dev)
+        code = C.dtype_code(total)
+        ws_bytes = lib.prl_rmsnorm_bwd_workspace_bytes(code, rows, h)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        with C.on_device(dev), C.timed("prl_add_rmsnorm_bwd", dev):
+            if gtotal is None:
+                C.check(lib.prl_rmsnorm_bwd(C.ptr(total), h, C.ptr(w), C.ptr(rstd), C.ptr(g2),
+                                            g2.stride(0) if rows > 1 else h, C.ptr(gx), h, C.ptr(gw), code, rows, h,
+                                            C.ptr(ws), ws_bytes, 0, 0, C.stream_ptr(dev)), "prl_rmsnorm_bwd")
+            else:
+                ga = rows16(gtotal)
+                C.check(lib.prl_add_rmsnorm_bwd(C.ptr(total), h, C.ptr(w), C.ptr(rstd), C.ptr(g2),
+                                                g2.stride(0) if rows > 1 else h, C.ptr(ga),
+                                                ga.stride(0) if rows > 1 else h, C.ptr(gx), h, C.ptr(gw), code, rows,
+                                                h, C.ptr(ws), ws_bytes, C.stream_ptr(dev)), "prl_add_rmsnorm_bwd")
+        gx = gx.view(ctx.shape)
+        return gx, gx, gw, None
+
+
+def add_rms_norm_supported(x: Tensor, branch: Tensor, weight: Tensor) -> bool:
+    """Whether `add_rms_norm` takes these tensors: what `rms_norm` takes, for two inputs of one shape."""
+    return x.shape == branch.shape and x.dtype == branch.dtype and x.ndim >= 2 \
+        and rms_norm_supported(x, weight) and rms_norm_supported(branch, weight) \
+        and _row_layout(x) is not None and _row_layout(x)[2] == 0 \
+        and _row_layout(branch) is not None and _row_layout(branch)[2] == 0
+
+
+def add_rms_norm(x: Tensor, branch: Tensor, weight: Tensor, eps: float) -> tuple[Tensor, Tensor]:
+    """(s, y) with s = x + branch (in their dtype) and y = rms_norm(s, weight, eps), differentiable in all three."""
+    return _AddRMSNorm.apply(x, branch, weight, float(eps))
+
+
 # --------------------------------------------------------------------------- rotary position embedding
 
 
@@ -391,7 +465,132 @@ _ORIGINAL_ROPE: list[Any] = []
 _PATCHED_MODULES: dict[str, Any] = {}
 
 
+class _Carry:
+    """What one block leaves for whoever reads its output next (the next block, or the final norm): its MLP
+    output, not yet added to the hidden states it returned, so that the addition runs inside that reader's
+    normalisation kernel.  Bound to the identity of the returned tensor: a reader that is handed anything else
+    while a branch is pending fails instead of computing without it."""
+
+    def __init__(self) -> None:
+        self.hidden: Tensor | None = None
+        self.branch: Tensor | None = None
+
+    def clear(self) -> None:
+        self.hidden = self.branch = None
+
+    def put(self, hidden: Tensor, branch: Tensor) -> None:
+        self.hidden, self.branch = hidden, branch
+
+    def take(self, hidden: Tensor) -> Tensor | None:
+        if self.branch is None:
+            return None
+        mine, branch = self.hidden is hidden, self.branch
+        self.clear()
+        if not mine:
+            raise RuntimeError("fused blocks: the output of a block was replaced before the next block or the final "
+                               "norm read it; the residual carry needs them called back to back "
+                               "(fused.enable_residual_carry(model, False) switches it off)")
+        return branch
+
+
+def _add_norm(norm: nn.Module, x: Tensor, branch: Tensor) -> tuple[Tensor, Tensor]:
+    """(x + branch, norm(x + branch)): one launch where the kernel takes the tensors, else the two steps."""
+    w = norm.weight
+    if not hasattr(w, "to_local") and add_rms_norm_supported(x, branch, w):
+        return add_rms_norm(x, branch, w, norm.variance_epsilon)
+    total = x + branch
+    return total, norm(total)
+
+
+def _fused_layer_forward(self: nn.Module, hidden_states: Tensor, attention_mask: Tensor | None = None,
+                         position_ids: Tensor | None = None, past_key_values: Any = None,
+                         use_cache: bool | None = False, position_embeddings: Any = None, **kwargs: Any) -> Tensor:
+    """The forward of a transformers decoder layer (residual, norm, attention, add, residual, norm, MLP, add) with
+    each addition inside the normalisation that follows it: the one after the attention always, the one after
+    the MLP when the layers hand it on (`enable_residual_carry`)."""
+    carry: _Carry | None = self._prl_carry
+    x = hidden_states
+    pending = None
+    if carry is not None:
+        if self._prl_first:
+            carry.clear()  # nothing of an earlier, abandoned forward
+        pending = carry.take(x)
+    if pending is not None:
+        x, normed = _add_norm(self.input_layernorm, x, pending)
+    else:
+        normed = self.input_layernorm(x)
+    branch, _ = self.self_attn(hidden_states=normed, attention_mask=attention_mask, position_ids=position_ids,
+                               past_key_values=past_key_values, use_cache=use_cache,
+                               position_embeddings=position_embeddings, **kwargs)
+    x, normed = _add_norm(self.post_attention_layernorm, x, branch)
+    branch = self.mlp(normed)
+    if carry is None:
+        return x + branch
+    carry.put(x, branch)
+    return x
+
+
+_LAYER_SHAPE = ("residual = hidden_states", "hidden_states = self.input_layernorm(hidden_states)",
+                "hidden_states = residual + hidden_states",
+                "hidden_states = self.post_attention_layernorm(hidden_states)",
+                "hidden_states = self.mlp(hidden_states)", "return hidden_states")
+
+
+def _is_plain_decoder_layer(module: nn.Module) -> bool:
+    """A decoder layer whose own forward is exactly the sequence `_fused_layer_forward` restates (Qwen3, Qwen2 and
+    Llama layers of this transformers version are; anything that adds a step is left alone)."""
+    if not type(module).__name__.endswith("DecoderLayer"):
+        return False
+    if not all(hasattr(module, a) for a in ("input_layernorm", "post_attention_layernorm", "self_attn", "mlp")):
+        return False
+    if not all(hasattr(n, "variance_epsilon") and hasattr(n, "weight")
+               for n in (module.input_layernorm, module.post_attention_layernorm)):
+        return False
+    import inspect
+
+    try:
+        lines = [ln.strip() for ln in inspect.getsource(type(module).forward).splitlines()]
+    except (OSError, TypeError):
+        return False
+    body = [ln for ln in lines if ln and not ln.startswith("#")]
+    pos = 0
+    for want in _LAYER_SHAPE:  # in this order, and the two additions both present
+        try:
+            pos = body.index(want, pos) + 1
+        except ValueError:
+            return False
+    return body.count("hidden_states = residual + hidden_states") == 2 and body.count("residual = hidden_states") == 2
+
+
+def enable_residual_carry(model: nn.Module, on: bool = True) -> int:
+    """Let every fused decoder layer hand its MLP output to the next layer's input norm (and the last layer's
+    to the final norm) instead of adding it itself.  Only for a model whose layers run back to back in one
+    process-local forward: not under per-layer activation checkpointing (a re-run layer would not get the branch
+    again) nor under per-layer FSDP (its pre-backward hook hangs on the layer's returned tensor, and the MLP's
+    backward can run before it).  Returns the number of layers that carry (0: the model is not shaped for it)."""
+    inner = getattr(model, "model", None)
+    layers = list(getattr(inner, "layers", []) or [])
+    final = getattr(inner, "norm", None)
+    ready = bool(layers) and final is not None and hasattr(final, "_prl_torch_forward") \
+        and all(hasattr(m, "_prl_carry") for m in layers)
+    if not on or not ready:
+        for m in [*layers, final]:
+            if m is not None and hasattr(m, "_prl_carry"):
+                m._prl_carry = None
+        return 0
+    carry = _Carry()
+    for i, m in enumerate(layers):
+        m._prl_carry, m._prl_first = carry, i == 0
+    final._prl_carry = carry
+    return len(layers)
+
+
 def _fused_rmsnorm_forward(self: nn.Module, hidden_states: Tensor) -> Tensor:
+    carry: _Carry | None = getattr(self, "_prl_carry", None)
+    if carry is not None:  # the final norm behind layers that carry their last addition
+        pending = carry.take(hidden_states)
+        if pending is not None:
+            return _add_norm(self, hidden_states, pending)[1]
     weight = self.weight
     if hasattr(weight, "to_local"):  # a DTensor outside an FSDP forward: leave it to torch
         return self._prl_torch_forward(hidden_states)
@@ -540,8 +739,11 @@ def _v_forward(self: nn.Module, x: Tensor) -> Tensor:
 def fuse_model(model: nn.Module) -> dict[str, int]:
     """Rebind the forward of every RMSNorm module of an HF causal LM to the HIP kernel.  Returns what was
     rebound, by kind.  Call it before FSDP wrapping or after; parameters are left as they are."""
-    done = {"rmsnorm": 0, "rope": 0, "swiglu": 0, "qkv": 0, "linear": 0}
+    done = {"rmsnorm": 0, "rope": 0, "swiglu": 0, "qkv": 0, "linear": 0, "layer": 0}
+    import os
     import sys
+
+    layers_too = os.environ.get("PRL_FUSED_LAYER", "1") != "0"  # the residual additions inside the norm kernels
 
     home = sys.modules.get(type(model).__module__)  # e.g. transformers.models.qwen3.modeling_qwen3
     if home is not None and hasattr(home, "apply_rotary_pos_emb"):
@@ -558,6 +760,11 @@ def fuse_model(model: nn.Module) -> dict[str, int]:
             module._prl_torch_forward = module.forward
             module.forward = types.MethodType(_fused_rmsnorm_forward, module)
             done["rmsnorm"] += 1
+        if layers_too and _is_plain_decoder_layer(module) and not hasattr(module, "_prl_torch_forward"):
+            module._prl_torch_forward = module.forward
+            module._prl_carry, module._prl_first = None, False
+            module.forward = types.MethodType(_fused_layer_forward, module)
+            done["layer"] += 1
         is_gated_mlp = name.endswith("MLP") and all(hasattr(module, a) for a in ("gate_proj", "up_proj", "down_proj")) \
             and type(getattr(module, "act_fn", None)).__name__ in ("SiLU", "SiLUActivation")
         if is_gated_mlp and not hasattr(module, "_prl_torch_forward"):
@@ -597,8 +804,9 @@ def unfuse_model(model: nn.Module) -> None:
         if hasattr(module, "_prl_torch_forward"):
             module.forward = module._prl_torch_forward
             del module._prl_torch_forward
-            if hasattr(module, "_prl_qkv"):
-                del module._prl_qkv
+            for attr in ("_prl_qkv", "_prl_carry", "_prl_first"):
+                if hasattr(module, attr):
+                    delattr(module, attr)
 
 
 def describe(model: nn.Module) -> Any:

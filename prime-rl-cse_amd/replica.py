@@ -348,6 +348,11 @@ class Replica:
         import os
 
         self.model = model
+        from . import fused
+
+        # layers that run back to back in this process, never re-run or sharded one by one: each hands its last
+        # residual addition to the next layer's norm kernel (0 when the model's blocks are not the fused ones)
+        self.residual_carry = fused.enable_residual_carry(model, os.environ.get("PRL_RESIDUAL_CARRY", "1") != "0")
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         if bucket_bytes == -1:
             bucket_bytes = int(float(os.environ.get("PRL_BUCKET_MB", "256")) * 2**20) or None

@@ -62,6 +62,77 @@ def test_rmsnorm_forward_and_backward(shape, dtype):
     assert torch.equal(x2.grad, x1.grad) and torch.equal(w2.grad, w1.grad)
 
 
+@pytest.mark.parametrize("shape", [(1, 2048, 1024), (1, 16384, 1024), (1, 37, 896), (3, 5, 3584), (1, 300, 4096)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_residual_addition_inside_the_norm_kernels_is_the_separate_addition(shape, dtype):
+    """add_rms_norm = an addition kernel + rms_norm forward, rms_norm backward + an addition kernel: bit for bit,
+    since the fused kernels round the sum and the input gradient to the storage type where the separate ones
+    store them."""
+    gen = torch.Generator().manual_seed(sum(shape) + 1)
+    mk = lambda *sh: torch.randn(*sh, generator=gen).to(dtype).to(DEV)
+    x, branch, gy, gs = mk(*shape), mk(*shape), mk(*shape), mk(*shape)
+    w = (1 + 0.1 * torch.randn(shape[-1], generator=gen)).to(dtype).to(DEV)
+    assert fused.add_rms_norm_supported(x, branch, w)
+
+    x1, b1, w1 = (t.clone().requires_grad_(True) for t in (x, branch, w))
+    s1, y1 = fused.add_rms_norm(x1, b1, w1, 1e-6)
+    torch.autograd.backward([s1, y1], [gs, gy])
+    x0, b0, w0 = (t.clone().requires_grad_(True) for t in (x, branch, w))
+    s0 = x0 + b0
+    y0 = fused.rms_norm(s0, w0, 1e-6)
+    torch.autograd.backward([s0, y0], [gs, gy])
+    assert torch.equal(s1, s0) and torch.equal(y1, y0)
+    assert torch.equal(x1.grad, x0.grad)
+    assert torch.equal(b1.grad, b0.grad)
+    assert torch.equal(w1.grad, w0.grad)
+    # one output unused: the gradient of the other alone
+    x2, b2, w2 = (t.clone().requires_grad_(True) for t in (x, branch, w))
+    fused.add_rms_norm(x2, b2, w2, 1e-6)[1].backward(gy)
+    x3, w3 = (x + branch).requires_grad_(True), w.clone().requires_grad_(True)
+    fused.rms_norm(x3, w3, 1e-6).backward(gy)
+    assert torch.equal(x2.grad, x3.grad) and torch.equal(b2.grad, x3.grad) and torch.equal(w2.grad, w3.grad)
+    x4, b4, w4 = (t.clone().requires_grad_(True) for t in (x, branch, w))
+    fused.add_rms_norm(x4, b4, w4, 1e-6)[0].backward(gs)
+    assert torch.equal(x4.grad, gs) and torch.equal(b4.grad, gs) and w4.grad is None
+
+
+def test_layers_that_carry_their_last_addition_give_the_model_without():
+    from prime_rl_cse_amd import trainer as T
+
+    cfg = T.model_config("Qwen/Qwen3-0.6B", num_layers=3)
+    model = T.get_model(cfg, DEV, torch.bfloat16, seed=0)
+    ids = torch.randint(0, 1000, (1, 96), device=DEV)
+    pos = torch.arange(32, device=DEV).repeat(3)[None]
+    done = fused.fuse_model(model)
+    assert done["layer"] == 3
+
+    def run():
+        model.zero_grad(set_to_none=True)
+        out = T.forward(model, ids, pos)
+        out.float().square().mean().backward()
+        return out, {n: p.grad.clone() for n, p in model.named_parameters()}
+
+    want, grads = run()  # every layer adds its own MLP output (the addition after the attention is in the norm)
+    assert fused.enable_residual_carry(model) == 3
+    got, carried = run()
+    assert torch.equal(got, want)
+    for n, g in grads.items():
+        assert torch.equal(carried[n], g), n
+    with torch.no_grad():
+        assert torch.equal(T.forward(model, ids, pos), want)
+    # a reader handed something else than the carrying layer's output fails instead of dropping the branch
+    layer = model.model.layers[1]
+    hidden = torch.randn(1, 96, cfg.hidden_size, device=DEV).to(torch.bfloat16)
+    cos_sin = model.model.rotary_emb(hidden, pos)
+    out = layer(hidden, position_embeddings=cos_sin, position_ids=pos)
+    with pytest.raises(RuntimeError, match="residual carry"):
+        model.model.norm(out.clone())
+    assert fused.enable_residual_carry(model, False) == 0
+    assert torch.equal(T.forward(model, ids, pos), want)
+    fused.unfuse_model(model)
+    assert fused.describe(model) == 0 and not hasattr(model.model.layers[0], "_prl_carry")
+
+
 def test_rmsnorm_rows_with_a_stride_and_unsupported_shapes():
     gen = torch.Generator().manual_seed(1)
     wide = torch.randn(64, 1024 + 64, generator=gen).to(torch.bfloat16).to(DEV)
@@ -161,7 +232,10 @@ def test_fuse_model_patches_rope_and_whole_model_agrees():
     finally:
         prl._capi.set_timer(None)
     torch.cuda.synchronize()
-    assert timer.summary()["prl_rope"]["launches"] == 2 and timer.summary()["prl_rmsnorm_fwd"]["launches"] == 9
+    seen = timer.summary()
+    assert seen["prl_rope"]["launches"] == 2
+    # per block: input, query and key norms alone, the post-attention norm together with the addition before it
+    assert seen["prl_rmsnorm_fwd"]["launches"] == 7 and seen["prl_add_rmsnorm_fwd"]["launches"] == 2
     assert (got - want).abs().max().item() <= 0.05 * want.abs().max().item() + 1e-3
     fused.unfuse_model(model)
     assert torch.equal(T.forward(model, ids, pos).float(), want)
@@ -251,7 +325,7 @@ def test_fuse_model_rebinds_the_gated_mlps():
     cfg = T.model_config("Qwen/Qwen3-0.6B", num_layers=3)
     model = T.get_model(cfg, DEV, torch.bfloat16, seed=3)
     done = fused.fuse_model(model)
-    assert done == {"rmsnorm": 13, "rope": 1, "swiglu": 3, "qkv": 3, "linear": 6}
+    assert done == {"rmsnorm": 13, "rope": 1, "swiglu": 3, "qkv": 3, "linear": 6, "layer": 3}
     ids = torch.randint(0, 1000, (1, 64), device=DEV)
     pos = torch.arange(64, device=DEV)[None]
     timer = prl._capi.KernelTimer()
