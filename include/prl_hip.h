@@ -370,6 +370,16 @@ int prl_accumulate_first(const void* const* src, int src_dtype, const int64_t* d
                    float* acc, void* stream);
 
 /*
+ * out[i] = part[0][i] + part[1][i] + ... + part[nparts - 1][i] for i < n, added in that order in fp32 and rounded
+ * once to bf16; the parts (fp32 or bf16) lie `part_stride` elements apart.  Last step of a weight gradient that
+ * was computed as a few batched products over ranges of the tokens of a long packed row (the reference leaves
+ * dW = gy^T x to one cuBLAS call inside autograd, src/prime_rl/trainer/rl/train.py:310).  n and part_stride
+ * multiples of 8, pointers 16-byte aligned.
+ */
+int prl_sum_parts(const void* parts, int parts_dtype, int64_t part_stride, int32_t nparts, int64_t n, void* out,
+                  void* stream);
+
+/*
  * Causal self-attention over a packed row of SHORT samples (each at most 128 tokens, head dimension 128,
  * bf16), hand-written for MFMA.  Stands where the reference's attention runs through flash-attn's
  * variable-length kernel (`attn_implementation = "flash_attention_2"` with position ids that restart per

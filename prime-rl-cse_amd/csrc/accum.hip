@@ -111,3 +111,74 @@ extern "C" int prl_accumulate_first(const void* const* src, int src_dtype, const
                                     int64_t n_chunks, const float* scale, float* acc, void* stream) {
   return accumulate(true, src, src_dtype, dst_offset, numel, chunk_tensor, chunk_start, n_chunks, scale, acc, stream);
 }
+
+// ---------------------------------------------------------------- sum of partial products
+//
+// out[i] = part[0][i] + part[1][i] + ... (in that order, fp32 arithmetic), rounded to bf16: the last step of a weight
+// gradient computed as a few batched products over ranges of the tokens (a long sum with a small output fills the
+// chip only when it is cut up).  One pass and one rounding, where a reduction followed by a type conversion reads
+// the partial results at half the memory rate and launches twice.
+namespace prl {
+
+template <int DTI>
+__global__ __launch_bounds__(256) void k_sum_parts(const char* __restrict__ parts, int64_t part_stride_bytes,
+                                                   int nparts, int64_t nvec, char* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // 8 consecutive outputs
+  if (i >= nvec) return;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+#pragma unroll 4
+  for (int p = 0; p < nparts; ++p) {
+    const char* src = parts + p * part_stride_bytes;
+    if constexpr (DTI == PRL_F32) {
+      const u32x4 a = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src) + 2 * i);
+      const u32x4 b = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src) + 2 * i + 1);
+      acc[0] += __uint_as_float(a.x), acc[1] += __uint_as_float(a.y);
+      acc[2] += __uint_as_float(a.z), acc[3] += __uint_as_float(a.w);
+      acc[4] += __uint_as_float(b.x), acc[5] += __uint_as_float(b.y);
+      acc[6] += __uint_as_float(b.z), acc[7] += __uint_as_float(b.w);
+    } else {
+      const u32x4 a = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src) + i);
+      const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[2 * j] += __uint_as_float(w[j] << 16);
+        acc[2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u);
+      }
+    }
+  }
+  u32x4 v;
+  v.x = pack_bf16(acc[0], acc[1]);
+  v.y = pack_bf16(acc[2], acc[3]);
+  v.z = pack_bf16(acc[4], acc[5]);
+  v.w = pack_bf16(acc[6], acc[7]);
+  reinterpret_cast<u32x4*>(out)[i] = v;
+}
+
+}  // namespace prl
+
+extern "C" int prl_sum_parts(const void* parts, int parts_dtype, int64_t part_stride, int32_t nparts, int64_t n,
+                             void* out, void* stream) {
+  using namespace prl;
+  clear_error();
+  PRL_REQUIRE(parts_dtype == PRL_F32 || parts_dtype == PRL_BF16, "sum_parts: partial results must be fp32 or bf16");
+  PRL_REQUIRE(nparts >= 1 && n >= 0 && n % 8 == 0 && part_stride >= n && part_stride % 8 == 0,
+              "sum_parts: bad sizes (%d parts of %lld, stride %lld; multiples of 8)", nparts, (long long)n,
+              (long long)part_stride);
+  if (n == 0) return PRL_OK;
+  PRL_REQUIRE(parts && out && ((reinterpret_cast<uintptr_t>(parts) | reinterpret_cast<uintptr_t>(out)) & 15) == 0,
+              "sum_parts: pointers must be 16-byte aligned and not NULL");
+  const int64_t nvec = n / 8;
+  PRL_REQUIRE((nvec + 255) / 256 <= 0x7fffffffLL, "sum_parts: too many elements");
+  const dim3 grid((unsigned)((nvec + 255) / 256)), block(256);
+  const int es = parts_dtype == PRL_F32 ? 4 : 2;
+  if (parts_dtype == PRL_F32)
+    hipLaunchKernelGGL((k_sum_parts<PRL_F32>), grid, block, 0, (hipStream_t)stream, (const char*)parts,
+                       part_stride * es, nparts, nvec, (char*)out);
+  else
+    hipLaunchKernelGGL((k_sum_parts<PRL_BF16>), grid, block, 0, (hipStream_t)stream, (const char*)parts,
+                       part_stride * es, nparts, nvec, (char*)out);
+  PRL_CHECK_LAUNCH("sum_parts");
+  return PRL_OK;
+}

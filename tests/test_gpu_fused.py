@@ -473,3 +473,24 @@ def test_weight_gradient_split_over_the_tokens():
         assert err <= 1.6 * base + 1e-4, (rows, n_out, n_in, err, base)
         if rows < 8192:
             assert torch.equal(got, one)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("nparts,n,stride", [(4, 1024 * 2048, 1024 * 2048), (2, 6144 * 1024, 6144 * 1024), (3, 40, 48),
+                                             (1, 8, 8), (5, 0, 0)])
+def test_partial_results_added_in_order_and_rounded_once(dtype, nparts, n, stride):
+    from prime_rl_cse_amd import _capi as C
+
+    gen = torch.Generator(device=DEV).manual_seed(nparts + n)
+    parts = torch.randn(nparts, max(stride, 8), generator=gen, device=DEV).to(dtype)
+    out = torch.full((max(n, 8),), 7.0, dtype=torch.bfloat16, device=DEV)
+    C.check(C.load().prl_sum_parts(C.ptr(parts), C.dtype_code(parts), stride, nparts, n, C.ptr(out), C.stream_ptr(out.device)),
+            "prl_sum_parts")
+    want = torch.zeros(n, dtype=torch.float32, device=DEV)
+    for p in range(nparts):  # this order, fp32, one rounding at the end
+        want = want + parts[p, :n].float()
+    assert torch.equal(out[:n], want.to(torch.bfloat16))
+    assert bool((out[n:] == 7.0).all())  # nothing past the end is written
+    lib = C.load()
+    assert lib.prl_sum_parts(C.ptr(parts), C.dtype_code(parts), stride, nparts, 12, C.ptr(out), C.stream_ptr(out.device)) != 0
+    assert lib.prl_sum_parts(C.ptr(parts), 7, stride, nparts, n, C.ptr(out), C.stream_ptr(out.device)) != 0
