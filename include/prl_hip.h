@@ -442,7 +442,8 @@ int prl_adamw_flat(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
  * writing q_out [T][q_heads][128] and k_out [T][k_heads][128] (contiguous) plus rstd [T][q_heads + k_heads].
  * The backward takes the gradients of q_out and k_out ({token stride, head stride} in elements, HOST arrays)
  * and writes the gradient with respect to y's query and key blocks INTO gy (same layout as y, pitch gy_pitch),
- * and gw [256] = the two norm weights' gradients (query's, then key's), in y's dtype.  cos / sin are
+ * and gw [256] = the two norm weights' gradients (query's, then key's), in y's dtype; gq and gk may be the query
+ * and key blocks of gy itself (the kernel then works in place).  cos / sin are
  * [T][128] with a token stride.  Head dimension 128 only.  These are the steps of the transformers attention
  * block between its projections and its attention call; the reference's switch for fused block kernels is
  * `model.impl = "liger_kernel"` (src/prime_rl/trainer/model.py:74-75).

@@ -142,9 +142,7 @@ class _AttnShort(torch.autograd.Function):
         hkv = k.shape[1]
         do = _kernel_ready(dout.transpose(1, 2))
         ov = out.transpose(1, 2)
-        dq = torch.empty((1, t, hq, d), dtype=q.dtype, device=dev).transpose(1, 2)
-        dk = torch.empty((1, t, hkv, d), dtype=q.dtype, device=dev).transpose(1, 2)
-        dv = torch.empty((1, t, hkv, d), dtype=q.dtype, device=dev).transpose(1, 2)
+        dq, dk, dv = _stacked_grads(t, hq, hkv, d, q.dtype, dev)
         delta = torch.empty((hq, t), dtype=torch.float32, device=dev)
         with C.on_device(dev), C.timed("prl_attn_short_bwd", dev):
             C.check(
@@ -155,6 +153,15 @@ class _AttnShort(torch.autograd.Function):
                 "prl_attn_short_bwd",
             )
         return dq, dk, dv, None, None, None
+
+
+def _stacked_grads(t: int, hq: int, hkv: int, d: int, dtype: torch.dtype, dev: torch.device):
+    """dq, dk, dv as [1, heads, t, d] views of ONE [t, (hq + 2 hkv) d] matrix, query heads first: the layout of the
+    gradient of a stacked q/k/v projection's output, so the block in front of the attention can take the three
+    as that matrix without copying (`fused._QKVNormRope.backward`); to anyone else they are three tensors."""
+    buf = torch.empty((1, t, hq + 2 * hkv, d), dtype=dtype, device=dev)
+    return (buf[:, :, :hq].transpose(1, 2), buf[:, :, hq : hq + hkv].transpose(1, 2),
+            buf[:, :, hq + hkv :].transpose(1, 2))
 
 
 class _AttnLong(torch.autograd.Function):
@@ -195,9 +202,7 @@ class _AttnLong(torch.autograd.Function):
         hkv = k.shape[1]
         do = _kernel_ready(dout.transpose(1, 2))
         ov = out.transpose(1, 2)
-        dq = torch.empty((1, t, hq, d), dtype=q.dtype, device=dev).transpose(1, 2)
-        dk = torch.empty((1, t, hkv, d), dtype=q.dtype, device=dev).transpose(1, 2)
-        dv = torch.empty((1, t, hkv, d), dtype=q.dtype, device=dev).transpose(1, 2)
+        dq, dk, dv = _stacked_grads(t, hq, hkv, d, q.dtype, dev)
         delta = torch.empty((hq, t), dtype=torch.float32, device=dev)
         with C.on_device(dev), C.timed("prl_attn_long_bwd", dev):
             C.check(

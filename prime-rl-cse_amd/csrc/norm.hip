@@ -601,13 +601,15 @@ __global__ __launch_bounds__(256) void k_qk_norm_rope_fwd(const char* __restrict
 
 // part[blockIdx.x][0..127] = this workgroup's column sums for the query norm's weight, [128..255] the key's
 template <int DT>
-__global__ __launch_bounds__(256) void k_qk_norm_rope_bwd(const char* __restrict__ gq, int64_t gq_ts, int64_t gq_hs,
-                                                          const char* __restrict__ gk, int64_t gk_ts, int64_t gk_hs,
+// gq / gk may be the query / key blocks of gy itself: a lane stores exactly the elements it loaded, after it
+// loaded them, so the three pointers carry no no-alias promise.
+__global__ __launch_bounds__(256) void k_qk_norm_rope_bwd(const char* gq, int64_t gq_ts, int64_t gq_hs,
+                                                          const char* gk, int64_t gk_ts, int64_t gk_hs,
                                                           const char* __restrict__ y, int64_t y_pitch,
                                                           const char* __restrict__ wq, const char* __restrict__ wk,
                                                           const float* __restrict__ rstd,
                                                           const char* __restrict__ cs, const char* __restrict__ sn,
-                                                          int64_t ct, char* __restrict__ gy, int64_t gy_pitch,
+                                                          int64_t ct, char* gy, int64_t gy_pitch,
                                                           float* __restrict__ part, int64_t T, int Hq, int Hk) {
   constexpr int ES = DT == PRL_F32 ? 4 : 2;
   constexpr int VE = 16 / ES;

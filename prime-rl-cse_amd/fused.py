@@ -606,6 +606,27 @@ def _fused_rmsnorm_forward(self: nn.Module, hidden_states: Tensor) -> Tensor:
     return self._prl_torch_forward(hidden_states)
 
 
+def _as_one_matrix(gq: Tensor | None, gk: Tensor | None, gv: Tensor | None, t: int, hq: int, hk: int, d: int,
+                   like: Tensor) -> Tensor | None:
+    """[t, (hq + 2 hk) d] over the memory of gq, gk, gv ([1, heads, t, d] each) when they are the query, key and
+    value blocks of exactly such a matrix, in that order, in `like`'s dtype and row width; else None."""
+    if gq is None or gk is None or gv is None:
+        return None
+    width = (hq + 2 * hk) * d
+    if like.shape != (t, width) or any(g.dtype != like.dtype or g.device != like.device for g in (gq, gk, gv)):
+        return None
+    es = like.element_size()
+    at = gq.data_ptr()
+    for g, heads in ((gq, hq), (gk, hk), (gv, hk)):
+        if g.shape != (1, heads, t, d) or g.stride()[1:] != (d, width, 1) or g.data_ptr() != at \
+                or g.untyped_storage().data_ptr() != gq.untyped_storage().data_ptr():
+            return None
+        at += heads * d * es
+    if gq.data_ptr() % 16:
+        return None
+    return torch.as_strided(gq, (t, width), (width, 1), gq.storage_offset())
+
+
 class _QKVNormRope(torch.autograd.Function):
     """Everything a Qwen3 attention block does between its input and its attention call, for one packed row:
     ONE product over the stacked q/k/v weights, one kernel for the query / key RMSNorm and the rotary embedding;
@@ -644,8 +665,13 @@ class _QKVNormRope(torch.autograd.Function):
         t, d = x2.shape[0], 128
         hq, hk = ctx.heads
         nqk = ctx.sizes[0] + ctx.sizes[1]
-        gy = torch.empty_like(y)
         gw = torch.empty(2 * d, dtype=y.dtype, device=dev)
+        # The three gradients as one matrix already (this package's attention kernels write them that way): the
+        # kernel then works in place on the query and key blocks and the value block is where it belongs.
+        gy = _as_one_matrix(gq, gk, gv, t, hq, hk, d, y)
+        in_place = gy is not None
+        if not in_place:
+            gy = torch.empty_like(y)
 
         def rows(g: Tensor, h: int) -> Tensor:  # [1, h, T, d] -> [T, h, d] with 16-byte aligned strides
             g = g.transpose(1, 2).reshape(t, h, d)
@@ -654,8 +680,11 @@ class _QKVNormRope(torch.autograd.Function):
                 g = g.contiguous()
             return g
 
-        gq3 = rows(gq, hq) if gq is not None else torch.zeros((t, hq, d), dtype=y.dtype, device=dev)
-        gk3 = rows(gk, hk) if gk is not None else torch.zeros((t, hk, d), dtype=y.dtype, device=dev)
+        if in_place:
+            gq3, gk3 = gy[:, : hq * d].view(t, hq, d), gy[:, hq * d : nqk].view(t, hk, d)
+        else:
+            gq3 = rows(gq, hq) if gq is not None else torch.zeros((t, hq, d), dtype=y.dtype, device=dev)
+            gk3 = rows(gk, hk) if gk is not None else torch.zeros((t, hk, d), dtype=y.dtype, device=dev)
         code = C.dtype_code(y)
         ws_bytes = lib.prl_qk_norm_rope_bwd_workspace_bytes(code, t, hq, hk)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
@@ -665,7 +694,9 @@ class _QKVNormRope(torch.autograd.Function):
                                              C.ptr(nk), C.ptr(rstd), C.ptr(cos2), C.ptr(sin2), cos2.stride(0),
                                              C.ptr(gy), gy.stride(0), C.ptr(gw), C.ptr(ws), ws_bytes, code, t, hq, hk,
                                              C.stream_ptr(dev)), "prl_qk_norm_rope_bwd")
-        if gv is not None:
+        if in_place:
+            pass
+        elif gv is not None:
             gy[:, nqk:].copy_(gv.transpose(1, 2).reshape(t, ctx.sizes[2]))
         else:
             gy[:, nqk:].zero_()

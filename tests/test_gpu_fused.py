@@ -458,6 +458,42 @@ def test_qk_norm_rope_function_against_the_separate_steps(dtype):
         assert (g - w).norm().item() <= tol * w.norm().item() + 1e-9, (name, (g - w).norm().item(), w.norm().item())
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_qk_norm_rope_backward_in_place_on_gradients_that_are_one_matrix(dtype):
+    """The attention kernels hand dq, dk, dv over as the blocks of one [T, (hq + 2 hk) d] matrix; `_QKVNormRope`
+    then runs its kernel in place and copies nothing.  Same bits as with three separate gradient tensors."""
+    from prime_rl_cse_amd import attention
+    from prime_rl_cse_amd.fused import _QKVNormRope, _as_one_matrix
+
+    t, hid, hq, hk, d = 200, 256, 8, 4, 128
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    rnd = lambda *sh: torch.randn(*sh, generator=gen, device=DEV)
+    x = rnd(1, t, hid).to(dtype)
+    w = (rnd((hq + 2 * hk) * d, hid) * hid ** -0.5).to(dtype)
+    nq, nk = (1.0 + 0.1 * rnd(d)).to(dtype), (1.0 + 0.1 * rnd(d)).to(dtype)
+    ang = torch.rand(1, t, d // 2, generator=gen, device=DEV) * 6.28
+    cos, sin = torch.cat([ang.cos(), ang.cos()], -1).to(dtype), torch.cat([ang.sin(), ang.sin()], -1).to(dtype)
+    grads = [rnd(1, h, t, d).to(dtype) for h in (hq, hk, hk)]
+    together = attention._stacked_grads(t, hq, hk, d, dtype, torch.device(DEV))
+    for dst, src in zip(together, grads):
+        dst.copy_(src)
+    assert _as_one_matrix(*together, t, hq, hk, d, torch.empty(t, (hq + 2 * hk) * d, dtype=dtype, device=DEV)) is not None
+    assert _as_one_matrix(*grads, t, hq, hk, d, torch.empty(t, (hq + 2 * hk) * d, dtype=dtype, device=DEV)) is None
+    assert _as_one_matrix(together[0], together[2], together[1], t, hq, hk, d,
+                          torch.empty(t, (hq + 2 * hk) * d, dtype=dtype, device=DEV)) is None
+
+    def run(gs):
+        xs = x.clone().requires_grad_(True)
+        wq, wk, wv = (p.detach().requires_grad_(True) for p in w.split([hq * d, hk * d, hk * d]))
+        a, b = nq.clone().requires_grad_(True), nk.clone().requires_grad_(True)
+        out = _QKVNormRope.apply(xs, fused.adjacent_rows(wq, wk, wv), wq, wk, wv, a, b, cos, sin, 1e-6)
+        torch.autograd.backward(list(out), list(gs))
+        return [z.grad for z in (xs, wq, wk, wv, a, b)]
+
+    for got, want in zip(run(together), run(grads)):
+        assert torch.equal(got, want)
+
+
 def test_weight_gradient_split_over_the_tokens():
     """`weight_grad` at a row long enough to be split, against the float32 product; and the short row left alone."""
     gen = torch.Generator(device=DEV).manual_seed(12)
