@@ -455,9 +455,22 @@ def launch_check(rank: int, world: int, backend: str, local: int) -> None:
         print(json.dumps({"metric": "launch_check", "value": float(x.item()), "unit": "sum of ranks",
                           "n_gpus": world, "backend": dist.get_backend(), "ranks": dist.get_world_size(),
                           "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0, "devices": names,
-                          "gpu_initialised": torch.cuda.is_initialized()}), flush=True)
+                          "gpu_initialised": torch.cuda.is_initialized()}), file=LINE_OUT, flush=True)
     dist.barrier()
     dist.destroy_process_group()
+
+
+LINE_OUT = sys.stdout  # where the one JSON line goes (main() points it at the real stdout)
+
+
+def keep_stdout_for_the_line() -> None:
+    """From here on file descriptor 1 of this process is its stderr, and `LINE_OUT` is the stdout it had: the
+    contract is ONE JSON line on stdout, and libraries print there too (RCCL writes a five-line version banner
+    to stdout when its first communicator is made, i.e. in every run with more than one rank)."""
+    global LINE_OUT
+    sys.stdout.flush()
+    LINE_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
 
 def main(argv: list[str] | None = None) -> int:
@@ -466,6 +479,7 @@ def main(argv: list[str] | None = None) -> int:
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` by itself: this process only starts the ranks and waits for them
         return launch_ranks(args.gpus, argv)
+    keep_stdout_for_the_line()
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -490,7 +504,7 @@ def main(argv: list[str] | None = None) -> int:
                 "config": {"workload": f"whole trainer step through the entry point, recipe {args.recipe}: {info['what']}",
                            "global_batch": world * info["rollouts_per_rank_and_step"], "seq_len": info["seq_len"],
                            "micro_batch": info["micro_batch_size"], "parallelism": f"dp{world}"},
-                "trainer_step": info}), flush=True)
+                "trainer_step": info}), file=LINE_OUT, flush=True)
         return 0
     local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
@@ -516,7 +530,7 @@ def main(argv: list[str] | None = None) -> int:
                                "global_batch": world * BATCH, "seq_len": SEQ_LEN, "micro_batch": MICRO_BATCH,
                                "parallelism": f"fsdp{world}"},
                     "trainer_step": info}
-            print(json.dumps(line), flush=True)
+            print(json.dumps(line), file=LINE_OUT, flush=True)
         if dist.is_initialized():
             dist.barrier()
             dist.destroy_process_group()
@@ -667,7 +681,7 @@ def main(argv: list[str] | None = None) -> int:
         with lock:
             if rank == 0 and not state["printed"]:
                 state["printed"] = True
-                print(json.dumps(line), flush=True)
+                print(json.dumps(line), file=LINE_OUT, flush=True)
 
     def bail() -> None:
         # a collective that never came back: the headline still goes out, the exit code says that the run hung

@@ -75,3 +75,19 @@ def test_the_hung_extra_has_a_nonzero_exit_code():
     assert bench.EXIT_TRAINER_EXTRA_HUNG != 0
     src = (REPO / "bench.py").read_text()
     assert "os._exit(EXIT_TRAINER_EXTRA_HUNG)" in src and "os._exit(0)" not in src
+
+
+def test_only_the_line_reaches_stdout_whatever_libraries_print():
+    """RCCL prints a version banner to file descriptor 1 when its first communicator is made; after
+    `keep_stdout_for_the_line` such output (and Python's own prints) lands on stderr and stdout carries the line."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    code = ("import os, bench; bench.keep_stdout_for_the_line(); os.write(1, b'RCCL version : x\\n'); "
+            "print('progress'); print('{\"metric\": \"m\"}', file=bench.LINE_OUT, flush=True)")
+    done = subprocess.run([sys.executable, "-c", code], cwd=Path(__file__).resolve().parent.parent,
+                          capture_output=True, text=True, timeout=120)
+    assert done.returncode == 0, done.stderr
+    assert done.stdout == '{"metric": "m"}\n'
+    assert "RCCL version : x" in done.stderr and "progress" in done.stderr
