@@ -264,10 +264,23 @@ class WeightPublisher:
                     full[k] = v.full_tensor() if isinstance(v, DTensor) else v
                 for fn in self._subscribers:
                     fn(full, step)
-                # 3. copy-out on rank 0
+                # 3. copy-out on rank 0: the floating tensors into slices of ONE pinned buffer that is kept and
+                # reused (a pinned allocation per tensor and publication is rounded up to a power of two by the
+                # host allocator and ran a 7B model out of lockable memory on the third publication)
                 if self._is_master:
+                    together = {k: v for k, v in full.items()
+                                if v.device.type == "cuda" and v.is_floating_point() and v.dtype == dtype}
+                    on_host: dict[str, Tensor] = {}
+                    if together:
+                        layout, total = self._layout(together, dtype)
+                        slot = self._host_slot(total, dtype)
+                        on_host = self._views(slot, layout)
+                        pending._slot = slot
                     for k, v in full.items():
-                        if v.device.type == "cuda":
+                        if k in on_host:
+                            on_host[k].copy_(v, non_blocking=True)
+                            host[k] = on_host[k]
+                        elif v.device.type == "cuda":
                             buf = self._host_buffer(v.shape, v.dtype)
                             buf.copy_(v, non_blocking=True)
                             host[k] = buf
