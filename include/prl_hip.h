@@ -236,6 +236,29 @@ int prl_policy_rows_fwd_bwd(const void* logits, int logits_dtype, int64_t T, int
                             void* stream);
 
 /*
+ * prl_policy_rows_fwd_bwd over GATHERED rows: the model's LM head was run only at the positions whose next token
+ * is scored, so `logits` holds R rows, row r being the logits at position positions[r] of a packed row of T tokens
+ * (it predicts token positions[r] + 1).  With prompts masked out of the loss (src/prime_rl/orchestrator/batch.py:21-62
+ * gives prompt tokens mask False) the reference still computes and differentiates the logits of every position
+ * (src/prime_rl/trainer/model.py:251-254, src/prime_rl/trainer/rl/train.py:285-310) although loss, gradient and
+ * every logged statistic use them only under the mask (loss.py:93, :104; train.py:313-315); leaving those rows out
+ * of the LM head's three products and out of this call changes none of them.
+ *
+ *   logits, dlogits  bf16 [R, V] (limits as prl_policy_rows_supported(.., R, ..) says)
+ *   positions        int64 [R], device; 0 <= positions[r] < T - 1, in any order, no position twice.  A row whose
+ *                    position is outside that range is not read and gets a zero gradient row.
+ *   ids, adv, old, mask, logprob, entropy, lse: [T], indexed by token, as for prl_policy_rows_fwd_bwd
+ * Every token that no row predicts comes back unscored (logprob = entropy = lse = 0), as skip_masked = 1 leaves a
+ * masked token; token 0 is scored against an all-zero row when mask[0] is set; a listed row whose token is masked
+ * out is not read (zero gradient row, token unscored).  R = 0 is allowed.  Follow with prl_policy_tail as usual.
+ */
+int prl_policy_rows_gathered_fwd_bwd(const void* logits, int logits_dtype, int64_t R, int64_t V, int64_t row_stride,
+                                     const int64_t* positions, int64_t T, const int64_t* ids, const float* adv,
+                                     const float* old, const uint8_t* mask, float temperature, float clip_ratio,
+                                     float loss_scale, float* logprob, float* entropy, float* lse, void* dlogits,
+                                     int out_dtype, int64_t out_row_stride, void* stream);
+
+/*
  * Sequence-mode forward AND backward of one packed row in a single pass over the logits (ratio_type "sequence":
  * one importance ratio per sample, src/prime_rl/trainer/rl/loss.py:92-96, 107-108; the chain replaced is the same
  * src/prime_rl/trainer/rl/train.py:285-310 as for prl_policy_rows_fwd_bwd).  A token's gradient needs the summed

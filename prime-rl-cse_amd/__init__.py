@@ -15,6 +15,7 @@ from .loss import (  # noqa: F401
     compute_entropy,
     compute_loss,
     policy_loss,
+    scored_positions,
     segments_from_position_ids,
     selective_log_softmax,
     shift_logits,

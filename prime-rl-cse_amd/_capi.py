@@ -84,6 +84,11 @@ SIGNATURES = {
         [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float,
          c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p],
     ),
+    "prl_policy_rows_gathered_fwd_bwd": (
+        c_int,
+        [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+         c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p],
+    ),
     "prl_scale_rows_if_not_one": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "prl_swiglu_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     "prl_swiglu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),

@@ -115,7 +115,8 @@ __global__ __launch_bounds__(kRowThreads) void k_policy_rows(
     const char* __restrict__ logits, int64_t T, int64_t V, int64_t in_stride_bytes, const int64_t* __restrict__ ids,
     const float* __restrict__ old, const float* __restrict__ adv, const uint32_t* __restrict__ mask_words,
     int mask_mis, int skip_masked, float inv_temp, float clip, float inv_scale, float* __restrict__ lp_out,
-    float* __restrict__ ent_out, float* __restrict__ lse_out, char* __restrict__ dlogits, int64_t out_stride_bytes) {
+    float* __restrict__ ent_out, float* __restrict__ lse_out, char* __restrict__ dlogits, int64_t out_stride_bytes,
+    const int64_t* __restrict__ positions, int64_t n_rows) {
   __shared__ float red_m[kRowWaves], red_s[kRowWaves], red_w[kRowWaves];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
 #if PRL_ROWS_XCD_BLOCKS
@@ -124,11 +125,14 @@ __global__ __launch_bounds__(kRowThreads) void k_policy_rows(
 #else
   const int64_t row = blockIdx.x;  // row of the logits and of the gradient
 #endif
-  if (row >= T) return;
+  if (row >= n_rows) return;
 #if PRL_ROWS_TRACE
   const uint64_t tick0 = wall_clock64();
 #endif
-  const int64_t t = row + 1;  // the token this row predicts
+  // The token this row predicts.  Whole packed row: row r holds the logits at position r (n_rows == T).  Gathered
+  // rows (`positions` given): row r holds the logits the model produced at position positions[r] of a packed row
+  // of T tokens; token 0 and the tokens no row predicts are the caller's business.
+  const int64_t t = positions ? positions[row] + 1 : row + 1;
   const int nchunk = (int)(V >> 3);
   const float c2 = inv_temp * kLog2e;
 
@@ -147,6 +151,10 @@ __global__ __launch_bounds__(kRowThreads) void k_policy_rows(
     for (int j = 0; j < NCH; ++j) store_chunk(z, out_rsrc, lane_off, j * kSlab);
   };
 
+  if (positions && (t < 1 || t >= T)) {  // a position outside the packed row: nothing is read, nothing is emitted
+    zero_row();
+    return;
+  }
   if (t >= T) {
     // the last row predicts nothing; its workgroup also emits token 0, which no row predicts
     if (tid == 0) {
@@ -1175,7 +1183,7 @@ extern "C" int prl_policy_rows_fwd_bwd(const void* logits, int logits_dtype, int
 #define PRL_ROWS(N)                                                                                                \
   hipLaunchKernelGGL((k_policy_rows<N>), grid, block, 0, st, (const char*)logits, T, V, row_stride * 2, ids, old, \
                      adv, mask_words, mask_mis, skip_masked ? 1 : 0, inv_temp, clip_ratio, 1.0f / scale, logprob, entropy, lse,   \
-                     (char*)dlogits, out_row_stride * 2)
+                     (char*)dlogits, out_row_stride * 2, (const int64_t*)nullptr, T)
 #endif
   // sizes at most kTailSlabs = 4 apart, so that the row always ends in the last 4 slabs of its kernel
   if (need <= 2)
@@ -1193,6 +1201,84 @@ extern "C" int prl_policy_rows_fwd_bwd(const void* logits, int logits_dtype, int
 #undef PRL_ROWS
   PRL_CHECK_LAUNCH("policy_rows_fwd_bwd");
   return PRL_OK;
+}
+
+namespace prl {
+// logprob, entropy and lse of a packed row before gathered rows are scored: 0 everywhere (a token no row predicts
+// is not scored), except token 0, which is scored against an all-zero row when its mask is set
+// (src/prime_rl/trainer/rl/loss.py:51-58).  A kernel, not a memset, so that a caller may capture the call.
+__global__ __launch_bounds__(256) void k_unscored_tokens(float* __restrict__ lp, float* __restrict__ ent,
+                                                         float* __restrict__ lse, const uint8_t* __restrict__ mask,
+                                                         int64_t T, int64_t V) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  if (t == 0 && mask[0] != 0)
+    emit_zero_row(V, 0, lp, ent, lse);
+  else
+    emit_skipped(t, lp, ent, lse);
+}
+}  // namespace prl
+
+extern "C" int prl_policy_rows_gathered_fwd_bwd(const void* logits, int logits_dtype, int64_t R, int64_t V,
+                                                int64_t row_stride, const int64_t* positions, int64_t T,
+                                                const int64_t* ids, const float* adv, const float* old,
+                                                const uint8_t* mask, float temperature, float clip_ratio,
+                                                float loss_scale, float* logprob, float* entropy, float* lse,
+                                                void* dlogits, int out_dtype, int64_t out_row_stride, void* stream) {
+  clear_error();
+#if PRL_ROWS_WALK
+  set_error("policy_rows_gathered_fwd_bwd: not built into a library with walking workgroups (PRL_ROWS_WALK)");
+  return PRL_EINVAL;
+#else
+  PRL_REQUIRE(T >= 1 && T < ((int64_t)1 << 31) && R >= 0 && R < ((int64_t)1 << 31),
+              "policy_rows_gathered_fwd_bwd: need 1 <= T < 2^31 tokens and 0 <= R < 2^31 rows");
+  PRL_REQUIRE(ids && adv && old && mask && logprob, "policy_rows_gathered_fwd_bwd: ids, adv, old, mask and logprob must not be NULL");
+  PRL_REQUIRE(temperature > 0.0f && temperature - temperature == 0.0f,
+              "policy_rows_gathered_fwd_bwd: temperature must be finite and positive");
+  PRL_REQUIRE(V >= 8, "policy_rows_gathered_fwd_bwd: V must be at least 8");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_unscored_tokens, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, logprob, entropy, lse,
+                     mask, T, V);
+  PRL_CHECK_LAUNCH("policy_rows_gathered_fwd_bwd (unscored tokens)");
+  if (R == 0) return PRL_OK;
+  PRL_REQUIRE(prl_policy_rows_supported(logits_dtype, R, V, row_stride, out_dtype, out_row_stride),
+              "policy_rows_gathered_fwd_bwd: shape or dtype not supported (needs bf16 in and out, V a multiple of 8 "
+              "and at most %d, row strides multiples of 8)",
+              kRowMaxChunks * kRowThreads * 8);
+  PRL_REQUIRE(logits && dlogits && positions, "policy_rows_gathered_fwd_bwd: logits, dlogits and positions must not be NULL");
+  PRL_REQUIRE(((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits)) & 15) == 0,
+              "policy_rows_gathered_fwd_bwd: logits and dlogits must be 16-byte aligned");
+  const float scale = loss_scale > 1.0f ? loss_scale : 1.0f;  // max(loss_scale, 1)
+  const float inv_temp = 1.0f / temperature;
+  const int need = chunks_needed(V);
+#if PRL_ROWS_XCD_BLOCKS
+  const dim3 grid((unsigned)((R + 7) / 8 * 8)), block(kRowThreads);
+#else
+  const dim3 grid((unsigned)R), block(kRowThreads);
+#endif
+  const int mask_mis = (int)(reinterpret_cast<uintptr_t>(mask) & 3);
+  const uint32_t* mask_words = reinterpret_cast<const uint32_t*>(mask - mask_mis);
+  // skip_masked = 1: a listed row whose token is masked out is not read; it gets a zero gradient row
+#define PRL_ROWS(N)                                                                                                \
+  hipLaunchKernelGGL((k_policy_rows<N>), grid, block, 0, st, (const char*)logits, T, V, row_stride * 2, ids, old, \
+                     adv, mask_words, mask_mis, 1, inv_temp, clip_ratio, 1.0f / scale, logprob, entropy, lse,      \
+                     (char*)dlogits, out_row_stride * 2, positions, R)
+  if (need <= 2)
+    PRL_ROWS(2);
+  else if (need <= 4)
+    PRL_ROWS(4);
+  else if (need <= 8)
+    PRL_ROWS(8);
+  else if (need <= 12)
+    PRL_ROWS(12);
+  else if (need <= 16)
+    PRL_ROWS(16);
+  else
+    PRL_ROWS(19);
+#undef PRL_ROWS
+  PRL_CHECK_LAUNCH("policy_rows_gathered_fwd_bwd");
+  return PRL_OK;
+#endif
 }
 
 extern "C" int prl_scale_rows_if_not_one(void* x, int dtype, int64_t T, int64_t V, int64_t row_stride,

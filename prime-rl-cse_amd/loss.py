@@ -369,13 +369,20 @@ class _PolicyLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, logits, input_ids, position_ids, advantages, old_logprobs, loss_mask, temperature,
-                loss_config, loss_scale, skip_masked):
+                loss_config, loss_scale, skip_masked, positions=None):
         dev = C.require_device(logits, input_ids, position_ids, advantages, old_logprobs, loss_mask)
         lib = C.load()
         logits = _rows(logits)
         _, t, v = logits.shape
         if t > 0 and logits.stride(1) < v:
             logits = logits.contiguous()
+        n_rows = t  # rows of logits; with gathered rows T is the length of the packed row they were taken from
+        if positions is not None:
+            C.require_device(positions)
+            positions = positions.reshape(-1).to(torch.int64).contiguous()
+            if positions.numel() != n_rows:
+                raise ValueError("policy_loss: `positions` must name one position per row of the logits")
+            t = input_ids.numel()
         ids = input_ids.reshape(-1).to(torch.int64).contiguous()
         pos = position_ids.reshape(-1).to(torch.int64).contiguous()
         adv, old, mask = _flat32(advantages), _flat32(old_logprobs), _u8(loss_mask)
@@ -394,8 +401,11 @@ class _PolicyLoss(torch.autograd.Function):
         single_pass = (
             not per_seq and t > 0 and ctx.needs_input_grad[0] and _rows_kernel_enabled()
             and logits.data_ptr() % 16 == 0
-            and bool(lib.prl_policy_rows_supported(code, t, v, logits.stride(1), code, v))
+            and bool(lib.prl_policy_rows_supported(code, max(n_rows, 1), v, logits.stride(1) if n_rows else v, code, v))
         )
+        if positions is not None and not single_pass:
+            raise ValueError("policy_loss: gathered rows (`positions`) need ratio_type 'token', bf16 logits that "
+                             "require a gradient, a vocabulary that is a multiple of 8 and at most 155648, and T > 0")
         seq_limits = _seq_rows_limits() if per_seq else None
         seq_pass = (
             per_seq and seq_limits is not None and t > 0 and ctx.needs_input_grad[0] and _rows_kernel_enabled()
@@ -440,6 +450,31 @@ class _PolicyLoss(torch.autograd.Function):
                     )
             ctx.dlogits = dlogits
             _LAST_SEQ_PENDING[0] = pending
+        elif single_pass and positions is not None:
+            # the LM head ran only where the next token is scored: row r of the logits belongs to position
+            # positions[r]; every per-token result still comes back in the packed row's layout
+            dlogits = torch.empty((1, n_rows, v), dtype=logits.dtype, device=dev)
+            with C.on_device(dev):
+                with C.timed("prl_policy_rows_gathered_fwd_bwd", dev):
+                    C.check(
+                        lib.prl_policy_rows_gathered_fwd_bwd(
+                            C.ptr(logits) if n_rows else None, code, n_rows, v, logits.stride(1) if n_rows else v,
+                            C.ptr(positions) if n_rows else None, t, C.ptr(ids), C.ptr(adv), C.ptr(old), C.ptr(mask),
+                            temperature, clip, float(loss_scale), at(0), at(1), at(2),
+                            C.ptr(dlogits) if n_rows else None, code, v, st,
+                        ),
+                        "prl_policy_rows_gathered_fwd_bwd",
+                    )
+                with C.timed("prl_policy_tail", dev):
+                    C.check(
+                        lib.prl_policy_tail(
+                            C.ptr(pos), at(0), C.ptr(old), C.ptr(adv), C.ptr(mask), t, ratio_code, length_norm, clip,
+                            float(loss_scale), at(8), at(4), at(5), at(6), at(3), at(7), None, C.c_void_p(ip),
+                            C.c_void_p(ip + 8 * (t + 1)), st,
+                        ),
+                        "prl_policy_tail",
+                    )
+            ctx.dlogits = dlogits
         elif single_pass:
             dlogits = torch.empty((1, t, v), dtype=logits.dtype, device=dev)
             with C.on_device(dev):
@@ -495,7 +530,7 @@ class _PolicyLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_loss, *_):
         if grad_loss is None:
-            return (None,) * 10
+            return (None,) * 11
         gscale = grad_loss.to(torch.float32).reshape(1).contiguous()
         if ctx.single_pass:
             d = ctx.dlogits
@@ -506,7 +541,7 @@ class _PolicyLoss(torch.autograd.Function):
             dev = d.device
             unit = _UNIT_GRADIENTS.get(dev)
             if unit is not None and grad_loss.data_ptr() == unit.data_ptr():
-                return (d,) + (None,) * 9  # the caller passed unit_gradient(): known to be 1
+                return (d,) + (None,) * 10  # the caller passed unit_gradient(): known to be 1
             _, t, v = d.shape
             with C.on_device(dev), C.timed("prl_scale_rows_if_not_one", dev):
                 C.check(
@@ -514,10 +549,10 @@ class _PolicyLoss(torch.autograd.Function):
                                                        C.stream_ptr(dev)),
                     "prl_scale_rows_if_not_one",
                 )
-            return (d,) + (None,) * 9
+            return (d,) + (None,) * 10
         logits, ids, lse, g = ctx.saved_tensors
         d = _launch_bwd(logits, ids, lse, g, gscale, ctx.temperature, True)
-        return (d,) + (None,) * 9
+        return (d,) + (None,) * 10
 
 
 def policy_loss(
@@ -531,6 +566,7 @@ def policy_loss(
     loss_config: Any,
     loss_scale: float,
     skip_masked: bool = False,
+    positions: Tensor | None = None,
 ) -> tuple[Tensor, dict[str, Tensor]]:
     """One micro-batch of the trainer's hot loop from the model's logits to a
     differentiable loss (src/prime_rl/trainer/rl/train.py:285-303) in one call
@@ -550,12 +586,19 @@ def policy_loss(
     pass that scores a row writes its gradient, and `.backward()` only hands
     it on.  The same holds for `ratio_type = "sequence"`: the workgroups of a sample exchange their log-ratios
     inside the launch (rows of samples longer than ~224 tokens, and rows whose wait ran out, take a second pass
-    over those rows only).  In every other case `.backward()` runs one more pass over the logits."""
+    over those rows only).  In every other case `.backward()` runs one more pass over the logits.
+
+    `positions` (int64 [R], on the device): the logits are GATHERED rows, [1, R, V]: the LM head was run only at
+    these positions of the packed row (`scored_positions` picks the ones whose next token is scored), row r
+    predicting token positions[r] + 1.  Everything per token still has T entries; tokens that no row predicts
+    come back unscored, as `skip_masked=True` leaves masked tokens, and the gradient is [1, R, V].  Token mode
+    with bf16 logits only.  With prompts masked out this takes their share out of the LM head's three products
+    and out of the pass over the logits; loss, gradient and masked statistics are unchanged."""
     if logits.ndim != 3 or logits.shape[0] != 1:
         raise ValueError(f"policy_loss takes one packed row, logits [1, T, V]; got {tuple(logits.shape)}")
     loss, lp, ent, ratio, clipped, is_clipped, seg_start, n_seg = _PolicyLoss.apply(
         logits, input_ids, position_ids, advantages, old_logprobs, loss_mask, float(temperature), loss_config,
-        float(loss_scale), bool(skip_masked),
+        float(loss_scale), bool(skip_masked), positions,
     )
     return loss, {
         "logprobs": lp,
@@ -566,3 +609,20 @@ def policy_loss(
         "seg_start": seg_start,
         "n_seg": n_seg,
     }
+
+
+def scored_positions(loss_mask: Tensor, multiple: int = 1) -> Tensor:
+    """Positions of a packed row whose logits are needed: p such that token p + 1 is scored (loss_mask[p + 1]),
+    ascending, as an int64 tensor on the mask's device (meant for a mask that is still on the host: no device
+    synchronisation then).  Token 0 is predicted by no position (the reference scores it against zeros,
+    src/prime_rl/trainer/rl/loss.py:51-58).
+
+    `multiple` > 1 rounds the count up with positions whose token is NOT scored (they cost a zero gradient row
+    each and change nothing), so that the LM head's products see few distinct row counts from step to step."""
+    m = loss_mask.reshape(-1).to(torch.bool)
+    keep = m[1:].clone()
+    n = int(keep.sum())
+    if multiple > 1 and n % multiple and n > 0:
+        spare = (~keep).nonzero().reshape(-1)[: multiple - n % multiple]
+        keep[spare] = True
+    return keep.nonzero().reshape(-1)

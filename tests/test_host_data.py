@@ -152,3 +152,18 @@ def test_two_ranks_each_load_their_own_shard_over_gloo(tmp_path):
     assert ids0 == [r["input_ids"][0].tolist() for r in per_rank[0]]
     assert ids1 == [r["input_ids"][0].tolist() for r in per_rank[1]]
     assert s0 == sum(int(r["loss_mask"].sum()) for r in per_rank[0])
+
+
+def test_scored_positions_are_the_positions_whose_next_token_is_scored():
+    import prime_rl_cse_amd as prl
+
+    mask = torch.tensor([[True, False, True, True, False, False, True, False]])
+    assert prl.scored_positions(mask).tolist() == [1, 2, 5]  # tokens 2, 3 and 6; token 0 has no position
+    assert prl.scored_positions(torch.zeros(1, 5, dtype=torch.bool)).numel() == 0
+    assert prl.scored_positions(torch.ones(1, 5, dtype=torch.bool)).tolist() == [0, 1, 2, 3]
+    # rounded up with positions nobody scores, never beyond the row, never when nothing is scored
+    padded = prl.scored_positions(mask, multiple=4)
+    assert padded.tolist() == [0, 1, 2, 5] and set([1, 2, 5]) <= set(padded.tolist())
+    assert prl.scored_positions(mask, multiple=16).tolist() == list(range(7))
+    assert prl.scored_positions(torch.zeros(1, 5, dtype=torch.bool), multiple=4).numel() == 0
+    assert prl.scored_positions(mask, multiple=3).tolist() == [1, 2, 5]
