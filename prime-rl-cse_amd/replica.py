@@ -428,10 +428,12 @@ class Replica:
         with torch.no_grad():
             rows = self.model.get_input_embeddings()(mb["input_ids"])
         rows.requires_grad_(True)
-        logits = forward(self.model, None, mb["position_ids"], plan, rows)
+        keep = mb.get("scored_positions")  # the LM head only where the next token is scored (`trainer.scored_rows`)
+        logits = forward(self.model, None, mb["position_ids"], plan, rows, positions=keep)
         # normaliser 1 here: the step's own normaliser multiplies the gradients when they are accumulated
         loss, aux = policy_loss(logits, mb["input_ids"], mb["position_ids"], mb["advantages"], mb["logprobs"],
-                                mb["loss_mask"], mb["temperature"], loss_config, 1.0, skip_masked=True)
+                                mb["loss_mask"], mb["temperature"], loss_config, 1.0, skip_masked=True,
+                                positions=keep)
         del logits
         loss.backward(unit_gradient(self.device))
         grads = [p.grad for p in self.state.params]
@@ -700,7 +702,7 @@ class Replica:
         fillers left out the same way (`trainer.scored`)."""
         from .trainer import (MERGE_MAX_TOKENS, StepResult, attention_plan, join_micro_batches, join_per_row,
                               add_ratio_statistics, local_loss_scale, ones_as_recomputed_error, restore_row_starts,
-                              scored)
+                              scored, scored_rows)
 
         join_tokens = MERGE_MAX_TOKENS if join_tokens is None else join_tokens
         t0 = time.perf_counter()
@@ -724,6 +726,10 @@ class Replica:
         grad_norm = None
         for step_idx, host_mb in enumerate(units):
             mb = to_device(host_mb, self.device)
+            if not self.graphs:  # (a captured pass is keyed by its shapes; the number of scored rows changes)
+                keep = scored_rows(host_mb, loss_config, self.model, self.device)
+                if keep is not None:
+                    mb["scored_positions"] = keep
             loss, aux = self.micro_batch(mb, attention_plan(host_mb, self.device), loss_config,
                                          last=step_idx == len(units) - 1)
             if step_idx == len(units) - 1:

@@ -171,6 +171,7 @@ def setup_fsdp(model: nn.Module, mesh: Any, reduce_dtype: torch.dtype = torch.fl
     if reshard_after_forward is None:  # not asked for either way: keep small models gathered
         reshard_after_forward = not keeps_parameters_gathered(model)
     model._prl_keep_gathered = not reshard_after_forward
+    model._prl_compute_dtype = torch.bfloat16  # what the blocks and the LM head compute in (the policy below)
     mp = MixedPrecisionPolicy(param_dtype=torch.bfloat16, reduce_dtype=reduce_dtype)
     blocks = list(model.model.layers)
     per = blocks_per_group if blocks_per_group else blocks_per_fsdp_group(model)
@@ -186,12 +187,15 @@ def setup_fsdp(model: nn.Module, mesh: Any, reduce_dtype: torch.dtype = torch.fl
 
 
 def forward(model: nn.Module, input_ids: Tensor | None, position_ids: Tensor, plan: Any = None,
-            inputs_embeds: Tensor | None = None) -> Tensor:
+            inputs_embeds: Tensor | None = None, positions: Tensor | None = None) -> Tensor:
     """Logits [batch, seq, vocab] of a packed row (src/prime_rl/trainer/model.py:251-254).  With a
     `attention.PackedPlan` of that row, attention runs over the samples side by side instead of over the
     whole row under a [T, T] mask; the logits are the same.  `inputs_embeds` (the rows of the embedding table,
-    already looked up) takes the place of `input_ids`."""
-    tokens = {"input_ids": input_ids} if inputs_embeds is None else {"inputs_embeds": inputs_embeds}
+    already looked up) takes the place of `input_ids`.  `positions` (int64 [R], on the device): the LM head runs
+    at these positions only and the logits are [batch, R, vocab] (`scored_rows`)."""
+    tokens: dict[str, Any] = {"input_ids": input_ids} if inputs_embeds is None else {"inputs_embeds": inputs_embeds}
+    if positions is not None:
+        tokens["logits_to_keep"] = positions  # transformers' causal LMs index the hidden states with it
     if plan is None:
         return model(position_ids=position_ids, **tokens).logits
     from . import attention
@@ -290,6 +294,50 @@ def scored(micro_batches: list[MicroBatch]) -> list[int]:
     still on the host here.  If no micro-batch has an unmasked token, all are kept (a step needs a pass)."""
     keep = [i for i, mb in enumerate(micro_batches) if bool(mb["loss_mask"].any())]
     return keep if keep else list(range(len(micro_batches)))
+
+
+GATHER_MULTIPLE = 256  # the number of gathered rows is rounded up to a multiple of this
+GATHER_AT_MOST = 0.9  # gather only when at most this share of a row's positions is left
+
+
+def scored_rows(host_micro_batch: MicroBatch, loss_config: LossConfig, model: nn.Module,
+                device: torch.device | str) -> Tensor | None:
+    """The positions of a packed row at which the LM head has to run, on the device, or None for "all of them".
+
+    The reference runs the LM head, the soft-max and their backward over every position of a row
+    (src/prime_rl/trainer/model.py:251-254, src/prime_rl/trainer/rl/train.py:285-310) and then uses the results
+    only under the loss mask (loss.py:93, :104; train.py:313-315); prompts are masked out
+    (src/prime_rl/orchestrator/batch.py:21-62), so a good part of a real row is computed for nothing.  A position
+    is needed iff the NEXT token is scored; the others are left out of the LM head's three products (forward,
+    input gradient, weight gradient) and of the pass over the logits.  Loss, gradients and logged statistics are
+    unchanged.  The mask is still on the host here, so picking the positions costs no synchronisation.
+
+    Only in token mode (with one ratio per sample the reference logs unmasked samples' ratios too), for a model
+    that computes bf16 logits over a vocabulary the one-pass row kernel handles, and only when at most
+    `GATHER_AT_MOST` of the positions is left (the count is rounded up to a multiple of `GATHER_MULTIPLE` with
+    positions nobody scores, so that the LM head's products meet few distinct sizes).  PRL_GATHER_SCORED=0
+    switches it off."""
+    import os
+
+    from . import _capi as C
+    from .loss import scored_positions
+
+    if os.environ.get("PRL_GATHER_SCORED", "1") == "0" or loss_config.ratio_type != "token":
+        return None
+    mask = host_micro_batch["loss_mask"]
+    if mask.is_cuda or mask.ndim != 2 or mask.shape[0] != 1 or mask.shape[1] < 2:
+        return None
+    dtype = getattr(model, "_prl_compute_dtype", None)
+    if dtype is None:
+        dtype = next(model.parameters()).dtype
+    vocab = int(getattr(getattr(model, "config", None), "vocab_size", 0))
+    if dtype != torch.bfloat16 or vocab < 8 or \
+            not C.load().prl_policy_rows_supported(C.PRL_BF16, 1, vocab, vocab, C.PRL_BF16, vocab):
+        return None
+    keep = scored_positions(mask, multiple=GATHER_MULTIPLE)
+    if keep.numel() == 0 or keep.numel() > GATHER_AT_MOST * (mask.shape[1] - 1):
+        return None
+    return host_to_device(keep, device, torch.int64)
 
 
 MERGE_MAX_TOKENS = 16384  # longest joined row (the one-launch loss kernel's limit, 5 GB of bf16 logits at V = 152 K)
@@ -476,11 +524,13 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, micro_batches
             model.set_reshard_after_backward(last)
         mb = to_device(host_mb, device)
         plan = attention_plan(host_mb, device)
+        keep = scored_rows(host_mb, loss_config, model, device)  # the LM head only where the next token is scored
         with plan_scope(plan):  # backward included: checkpointed blocks run their forward again in there
-            logits = forward(model, mb["input_ids"], mb["position_ids"], plan)
+            logits = forward(model, mb["input_ids"], mb["position_ids"], plan, positions=keep)
             vocab = int(logits.shape[-1])
             loss, aux = policy_loss(logits, mb["input_ids"], mb["position_ids"], mb["advantages"], mb["logprobs"],
-                                    mb["loss_mask"], mb["temperature"], loss_config, loss_scale, skip_masked=True)
+                                    mb["loss_mask"], mb["temperature"], loss_config, loss_scale, skip_masked=True,
+                                    positions=keep)
             del logits
             loss.backward(unit_gradient(loss.device))
         if rows is not None:

@@ -442,3 +442,47 @@ def test_exchange_inside_backward_over_rccl_leaves_the_single_rank_step_unchange
         assert n1 == pytest.approx(n0, rel=1e-6) and l1 == pytest.approx(l0, rel=1e-6, abs=1e-9)
         for a, b in zip(p0, p1):
             torch.testing.assert_close(b, a, rtol=1e-6, atol=1e-8)
+
+
+def test_lm_head_only_where_the_next_token_is_scored(monkeypatch):
+    """With prompts masked out, the LM head and the pass over the logits run only at positions whose next token
+    is scored (`trainer.scored_rows`): the steps are those of the run over every position, up to what bf16
+    products of another shape round differently."""
+    import prime_rl_cse_amd.replica as R
+    from prime_rl_cse_amd.optim import FlatAdamW
+
+    gen = torch.Generator().manual_seed(41)
+    loss_cfg = prl.LossConfig()
+    batches = []
+    for _ in range(3):
+        mbs = rows(gen, 3, [32, 32, 32, 32], 4096)
+        for mb in mbs:  # a prompt of 20 tokens in front of every sample, a few more tokens masked at random
+            mb["loss_mask"] = mb["loss_mask"] & (mb["position_ids"] >= 20)
+        batches.append(mbs)
+    seen = []
+    real = R.policy_loss
+
+    def spy(logits, *args, **kw):
+        seen.append((tuple(logits.shape), None if kw.get("positions") is None else int(kw["positions"].numel())))
+        return real(logits, *args, **kw)
+
+    monkeypatch.setattr(R, "policy_loss", spy)
+    results = []
+    for gather in ("0", "1"):
+        monkeypatch.setenv("PRL_GATHER_SCORED", gather)
+        model = T.get_model(tiny_config(vocab=4096), DEV, torch.float32, seed=11)
+        rep = Replica(model, lambda m: FlatAdamW(m.parameters(), lr=1e-3, weight_decay=0.01))
+        out = []
+        for mbs in batches:
+            res = rep.train_step(copy.deepcopy(mbs), loss_cfg, max_norm=1.0)
+            out.append((res, rep.state.master.detach().clone()))
+        results.append(out)
+    # three rows of 128 tokens joined and rounded up to 512; under a third of them scored, rounded up to 256 rows
+    assert seen[:3] == [((1, 512, 4096), None)] * 3 and seen[3:] == [((1, 256, 4096), 256)] * 3
+    for i, ((r0, m0), (r1, m1)) in enumerate(zip(*results)):
+        assert r1.tokens == r0.tokens == 384 and r1.passes == r0.passes == 1
+        assert r1.grad_norm == pytest.approx(r0.grad_norm, rel=5e-3 * (i + 1))
+        assert r1.stats.keys() == r0.stats.keys()
+        for k in r0.stats:
+            assert r1.stats[k] == pytest.approx(r0.stats[k], rel=5e-3 * (i + 1), abs=1e-6), k
+        assert (m1 - m0).norm().item() <= 0.3 * 1e-3 * m0.numel() ** 0.5 * (i + 1)

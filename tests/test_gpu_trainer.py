@@ -400,3 +400,43 @@ def test_once_per_step_collectives_give_the_per_micro_batch_gradients(monkeypatc
     finally:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def test_gathered_lm_head_rows_in_the_plain_trainer_step(monkeypatch):
+    """`trainer.train_step` on a bf16 model whose rows have their prompts masked out: with the LM head run only
+    where the next token is scored the step's statistics and gradients are those of the run over every position
+    (to bf16 rounding of products of another shape); an fp32 model never gathers."""
+    import prime_rl_cse_amd.trainer as TT
+
+    cfg = tiny_config()
+    gen = torch.Generator().manual_seed(8)
+    mbs = rows(gen, 3, [40, 24, 64], cfg.vocab_size)
+    for mb in mbs:
+        mb["loss_mask"] = mb["loss_mask"] & (mb["position_ids"] >= 16)
+    seen = []
+    real = TT.policy_loss
+
+    def spy(logits, *args, **kw):
+        seen.append(None if kw.get("positions") is None else int(kw["positions"].numel()))
+        return real(logits, *args, **kw)
+
+    monkeypatch.setattr(TT, "policy_loss", spy)
+    out = []
+    for gather, dtype in (("0", torch.bfloat16), ("1", torch.bfloat16), ("1", torch.float32)):
+        monkeypatch.setenv("PRL_GATHER_SCORED", gather)
+        model = T.get_model(cfg, DEV, dtype, seed=4)
+        captured = {}
+        hooks = [p.register_post_accumulate_grad_hook(lambda q, n=n: captured.__setitem__(n, q.grad.float().clone()))
+                 for n, p in model.named_parameters()]
+        res = T.train_step(model, torch.optim.SGD(model.parameters(), lr=0.0), copy.deepcopy(mbs), prl.LossConfig(),
+                           max_norm=1e9, device=DEV)
+        for h in hooks:
+            h.remove()
+        out.append((res, captured))
+    assert seen == [None, 256, None]  # 384 tokens joined, rounded up to 512; 256 gathered rows
+    (r0, g0), (r1, g1), _ = out
+    assert r1.grad_norm == pytest.approx(r0.grad_norm, rel=2e-2)
+    for k in r0.stats:
+        assert r1.stats[k] == pytest.approx(r0.stats[k], rel=5e-3, abs=1e-5), k
+    for n in g0:
+        assert (g1[n] - g0[n]).norm().item() <= 3e-2 * g0[n].norm().item() + 1e-9, n
