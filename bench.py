@@ -387,6 +387,9 @@ def rank_commands(n: int, argv: list[str], port: int, environ: dict[str, str] | 
         env = {**base, "RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
                "GROUP_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "PYTHONUNBUFFERED": "1",
                "PRL_BENCH_LAUNCHED": "1"}
+        # the host driver of these nodes shares device memory between processes through dmabuf only: without this
+        # RCCL's set-up fails in hipIpcGetMemHandle (kept as it is when the caller has set it)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         out.append(([sys.executable, "-u", str(Path(__file__).resolve()), *argv], env))
     return out
 

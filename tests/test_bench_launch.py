@@ -25,7 +25,7 @@ def test_rank_commands_carry_the_rendezvous_of_one_node():
         assert env["RANK"] == env["LOCAL_RANK"] == str(r)
         assert env["WORLD_SIZE"] == env["LOCAL_WORLD_SIZE"] == "4"
         assert env["MASTER_ADDR"] == "127.0.0.1" and env["MASTER_PORT"] == "29999"
-        assert env["HOME"] == "/x"
+        assert env["HOME"] == "/x" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
 def test_two_ranks_meet_over_gloo_and_one_line_comes_out():
