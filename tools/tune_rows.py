@@ -25,6 +25,12 @@ VARIANTS = {
     "walking_workgroups": {"PRL_ROWS_WALK": 1},
     "walking_reads_in_the_write_stream": {"PRL_ROWS_WALK": 1, "PRL_ROWS_INTERLEAVE": 1},
     "trace": {"PRL_ROWS_TRACE": 1},
+    # cache-policy bits of the gradient stores: nt + sc1 (written through the L2 at device scope), sc1 alone,
+    # sc0 + sc1 (system scope), nt + sc0 + sc1
+    "store_nt_sc1": {"PRL_ROWS_STORE_AUX": 18},
+    "store_sc1": {"PRL_ROWS_STORE_AUX": 16},
+    "store_sc0_sc1": {"PRL_ROWS_STORE_AUX": 17},
+    "store_nt_sc0_sc1": {"PRL_ROWS_STORE_AUX": 19},
 }
 
 
@@ -32,7 +38,7 @@ def build() -> None:
     subprocess.run(["make", "-C", str(CSRC), "-j8"], check=True)
     TUNE.mkdir(parents=True, exist_ok=True)
     others = [str(LIB / "obj" / f"{n}.o") for n in ("capi", "logprob", "segments", "loss", "advantage", "stats", "policy",
-                                                      "norm", "accum", "attn_short", "optim")]
+                                                      "norm", "accum", "attn_short", "attn_long", "optim")]
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Xclang", "-target-feature", "-Xclang",
              "-packed-fp32-ops", f"-I{REPO / 'include'}", f"-I{CSRC}"]
     for tag, defs in VARIANTS.items():
@@ -57,12 +63,18 @@ def run(rounds: int = 15, t: int = 2048, v: int = 151936) -> None:
     logits = torch.empty(t, v, dtype=torch.bfloat16, device=dev)
     for r in range(0, t, 512):
         logits[r : r + 512] = (torch.randn(min(512, t - r), v, generator=g, device=dev) * 2.5).to(torch.bfloat16)
+    # the calls of a round walk over several copies of the logits and several gradient buffers, as the benchmark's
+    # eight micro-batches do: with one buffer a good part of it stays in the 256 MB Infinity Cache between calls
+    sets = 5
+    logits_sets = [logits] + [logits.clone() for _ in range(sets - 1)]
     ids = torch.randint(0, v, (t,), generator=g, device=dev)
     adv = torch.where(torch.rand(t, generator=g, device=dev) < 0.5, -0.5, 0.5)
     old = torch.full((t,), -12.0, device=dev)
     mask = torch.ones(t, dtype=torch.uint8, device=dev)
     lp, ent, lse = (torch.empty(t, device=dev) for _ in range(3))
-    out = torch.empty(t, v, dtype=torch.bfloat16, device=dev)
+    out_sets = [torch.empty(t, v, dtype=torch.bfloat16, device=dev) for _ in range(sets)]
+    out = out_sets[0]
+    turn = [0]
     st = C.stream_ptr(dev)
     libs = {}
     for path in sorted(TUNE.glob("librows_*.so")):  # every build in the directory, also hand-placed ones
@@ -72,8 +84,9 @@ def run(rounds: int = 15, t: int = 2048, v: int = 151936) -> None:
         libs[path.stem[len("librows_"):]] = fn
 
     def call(fn):
-        rc = fn(C.ptr(logits), C.PRL_BF16, t, v, v, C.ptr(ids), C.ptr(adv), C.ptr(old), C.ptr(mask), 0, 1.0, 1e30,
-                float(t), C.ptr(lp), C.ptr(ent), C.ptr(lse), C.ptr(out), C.PRL_BF16, v, st)
+        k = turn[0] = (turn[0] + 1) % sets
+        rc = fn(C.ptr(logits_sets[k]), C.PRL_BF16, t, v, v, C.ptr(ids), C.ptr(adv), C.ptr(old), C.ptr(mask), 0, 1.0,
+                1e30, float(t), C.ptr(lp), C.ptr(ent), C.ptr(lse), C.ptr(out_sets[k]), C.PRL_BF16, v, st)
         assert rc == 0
 
     # old = lp so that every token has a gradient: one warm call per variant fills lp
