@@ -150,6 +150,45 @@ __global__ __launch_bounds__(NT) void k_logprob_bwd_flat(const char* __restrict_
   }
 }
 
+// The same pieces, one per workgroup on a (pieces per row, rows) grid: a workgroup handles NT * UPT units and ends.
+// Workgroups start in the order of their index (x fastest), so the grid as a whole still sweeps the logits and the
+// gradient front to back, and no wave lives longer than one load and one store per unit.
+template <int DTI, int DTO, int NT, int UPT>
+__global__ __launch_bounds__(NT) void k_logprob_bwd_once(const char* __restrict__ logits, int64_t T, int64_t V,
+                                                         int64_t in_stride_bytes, const int64_t* __restrict__ ids,
+                                                         const float* __restrict__ lse, const float* __restrict__ g,
+                                                         const float* __restrict__ gscale, float inv_temp, int shift,
+                                                         char* __restrict__ out, int64_t out_stride_bytes) {
+  constexpr int U = (DTI == PRL_BF16 || DTO == PRL_BF16) ? 8 : 4;
+  constexpr int RAW = DTI == PRL_F32 ? U / 4 : 1;
+  const int64_t nunit = V / U;
+  const int64_t row = blockIdx.y;
+  const int64_t t = row + shift;
+  const float gi = t < T ? g[t] * ((gscale ? gscale[0] : 1.0f) * inv_temp) : 0.0f;
+  const char* inp = logits + row * in_stride_bytes;
+  char* outp = out + row * out_stride_bytes;
+  const int64_t u0 = (int64_t)blockIdx.x * (NT * UPT) + threadIdx.x;
+  if (gi == 0.0f) {
+    float z[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) z[j] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < UPT; ++q)
+      if (u0 + q * NT < nunit) store_unit<DTO, U, PRL_BWD_ONCE_NT_STORE != 0>(outp, u0 + q * NT, z);
+    return;
+  }
+  const float c = inv_temp * kLog2e;
+  const float lse2 = lse[t] * kLog2e;
+  const int64_t label = ids[t];
+  u32x4 raw[UPT][RAW];
+#pragma unroll
+  for (int q = 0; q < UPT; ++q)
+    if (u0 + q * NT < nunit) load_unit<DTI, U>(inp, u0 + q * NT, raw[q]);
+#pragma unroll
+  for (int q = 0; q < UPT; ++q)
+    if (u0 + q * NT < nunit) bwd_unit<DTI, DTO, U, PRL_BWD_ONCE_NT_STORE != 0>(raw[q], outp, u0 + q * NT, c, lse2, gi, label);
+}
+
 // grid.x = rows * nsplit; workgroup (row, k) covers elements [k*chunk, (k+1)*chunk) of the row.
 template <int DTI, int DTO, int NT>
 __global__ __launch_bounds__(NT) void k_logprob_bwd(const char* __restrict__ logits, int64_t T, int64_t V,
@@ -249,7 +288,17 @@ constexpr int64_t kMinChunk = 8192;     // do not split a row into pieces smalle
 constexpr int kMaxSplit = 64;
 
 static int pick_split(int64_t T, int64_t V) {
-  if (T <= 0 || T >= kFillBlocks / 2) return 1;
+  if (T <= 0) return 1;
+  if (T >= kFillBlocks / 2) {
+#if PRL_FWD_SPLIT_PIECE > 0
+    // many rows: the chip is full either way; pieces of about one trip per workgroup keep every wave short-lived
+    int64_t want = (V + PRL_FWD_SPLIT_PIECE - 1) / PRL_FWD_SPLIT_PIECE;
+    if (want > kMaxSplit) want = kMaxSplit;
+    return want < 1 ? 1 : (int)want;
+#else
+    return 1;
+#endif
+  }
   int64_t want = (kFillBlocks + T - 1) / T;
   int64_t cap = V / kMinChunk;
   if (cap < 1) cap = 1;
@@ -325,6 +374,9 @@ extern "C" int prl_logprob_entropy_fwd_static(const void* logits, int logits_dty
       g_scratch_ptr[dev] = ptr;
     }
   }
+  if (T >= kFillBlocks / 2)  // many rows: one workgroup per row, which needs no scratch at all
+    return logprob_fwd_impl(logits, logits_dtype, T, V, row_stride, ids, temperature, shift, nullptr, logprob, entropy,
+                            lse, nullptr, 0, stream);
   const size_t need = prl_logprob_workspace_bytes(T, V);
   if (need > kStaticScratchBytes) {
     set_error("logprob_entropy_fwd_static: T=%lld V=%lld needs %zu bytes of scratch, the static array holds %zu; "
@@ -460,6 +512,27 @@ static int logprob_bwd_impl(const void* logits, int logits_dtype, int64_t T, int
                                             (uintptr_t)sbi | (uintptr_t)sbo) & 15) == 0;
     // (with a selection of rows: one workgroup per row, which looks at its row's mark and leaves at once)
     if (flat_ok && !row_select) {
+#if PRL_BWD_ONCE
+      if (T <= 65535) {  // (the grid's second dimension holds the rows)
+        constexpr int OUPT = PRL_BWD_ONCE_UPT;
+        const int64_t oppr = (V / unit + (int64_t)kBwdThreads * OUPT - 1) / ((int64_t)kBwdThreads * OUPT);
+        const dim3 ogrid((unsigned)oppr, (unsigned)T), oblock(kBwdThreads);
+#define PRL_BWDO(DI, DO)                                                                                          \
+  hipLaunchKernelGGL((k_logprob_bwd_once<DI, DO, kBwdThreads, OUPT>), ogrid, oblock, 0, st, lg, T, V, sbi, ids, lse, \
+                     g, gscale, inv_temp, shift, out, sbo)
+        if (logits_dtype == PRL_F32 && out_dtype == PRL_F32)
+          PRL_BWDO(PRL_F32, PRL_F32);
+        else if (logits_dtype == PRL_F32)
+          PRL_BWDO(PRL_F32, PRL_BF16);
+        else if (out_dtype == PRL_F32)
+          PRL_BWDO(PRL_BF16, PRL_F32);
+        else
+          PRL_BWDO(PRL_BF16, PRL_BF16);
+#undef PRL_BWDO
+        PRL_CHECK_LAUNCH("logprob_bwd(once)");
+        return PRL_OK;
+      }
+#endif
       constexpr int UPT = PRL_BWD_FLAT_UPT;
       const int64_t per_piece = (int64_t)kBwdThreads * UPT;
       const int64_t ppr = (V / unit + per_piece - 1) / per_piece;

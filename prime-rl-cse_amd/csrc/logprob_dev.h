@@ -31,11 +31,23 @@
 #ifndef PRL_FWD_UNR
 #define PRL_FWD_UNR 4  // 16-byte loads in flight per lane in the forward
 #endif
+#ifndef PRL_FWD_SPLIT_PIECE
+#define PRL_FWD_SPLIT_PIECE 0  // > 0: also with many rows the forward splits every row into pieces of about this many elements
+#endif
 #ifndef PRL_BWD_LOADS
 #define PRL_BWD_LOADS 4  // 16-byte loads per lane and iteration in the backward
 #endif
 #ifndef PRL_BWD_FLAT
 #define PRL_BWD_FLAT 1  // 1: flat grid-stride backward when the layout allows it, else one workgroup per row
+#endif
+#ifndef PRL_BWD_ONCE
+#define PRL_BWD_ONCE 1  // 1: the flat backward as one piece per workgroup on a (pieces, rows) grid, no grid stride
+#endif
+#ifndef PRL_BWD_ONCE_UPT
+#define PRL_BWD_ONCE_UPT 1  // work units per thread in that form
+#endif
+#ifndef PRL_BWD_ONCE_NT_STORE
+#define PRL_BWD_ONCE_NT_STORE 1  // non-temporal hint on that form's stores
 #endif
 #ifndef PRL_BWD_FLAT_UPT
 #define PRL_BWD_FLAT_UPT 2  // work units per thread and piece in the flat backward
@@ -54,12 +66,13 @@ __device__ __forceinline__ u32x4 stream_load(const u32x4* p) {
     return *p;
   }
 }
+template <bool NT = (PRL_NT_STORE != 0)>
 __device__ __forceinline__ void stream_store(u32x4 v, u32x4* p) {
-#if PRL_NT_STORE
-  __builtin_nontemporal_store(v, p);
-#else
-  *p = v;
-#endif
+  if constexpr (NT) {
+    __builtin_nontemporal_store(v, p);
+  } else {
+    *p = v;
+  }
 }
 
 // Running soft-max statistics of the raw logits x seen so far.  With c = log2(e) / temperature
@@ -272,7 +285,7 @@ __device__ __forceinline__ void store_elem(char* p, int64_t i, float v) {
 }
 
 // U values -> 16-byte stores
-template <int DTO, int U>
+template <int DTO, int U, bool NTS = (PRL_NT_STORE != 0)>
 __device__ __forceinline__ void store_unit(char* outp, int64_t unit, const float* d) {
   if constexpr (DTO == PRL_F32) {
     u32x4* o = reinterpret_cast<u32x4*>(outp) + unit * (U / 4);
@@ -283,7 +296,7 @@ __device__ __forceinline__ void store_unit(char* outp, int64_t unit, const float
       v.y = __float_as_uint(d[4 * q + 1]);
       v.z = __float_as_uint(d[4 * q + 2]);
       v.w = __float_as_uint(d[4 * q + 3]);
-      stream_store(v, o + q);
+      stream_store<NTS>(v, o + q);
     }
   } else {
     static_assert(U == 8 || DTO == PRL_F32, "bf16 output works on units of 8");
@@ -292,7 +305,7 @@ __device__ __forceinline__ void store_unit(char* outp, int64_t unit, const float
     v.y = pack_bf16(d[2], d[3]);
     v.z = pack_bf16(d[4], d[5]);
     v.w = pack_bf16(d[6], d[7]);
-    stream_store(v, reinterpret_cast<u32x4*>(outp) + unit);
+    stream_store<NTS>(v, reinterpret_cast<u32x4*>(outp) + unit);
   }
 }
 
@@ -318,7 +331,7 @@ __device__ __forceinline__ void decode_unit(const u32x4* raw, float c, float* y)
 }
 
 // The math of one work unit: d = -gi * 2^(y - lse2), plus gi at the label, then the store.
-template <int DTI, int DTO, int U>
+template <int DTI, int DTO, int U, bool NTS = (PRL_NT_STORE != 0)>
 __device__ __forceinline__ void bwd_unit(const u32x4* raw, char* outp, int64_t unit, float c, float lse2, float gi,
                                          int64_t label) {
   float y[U], d[U];
@@ -330,7 +343,7 @@ __device__ __forceinline__ void bwd_unit(const u32x4* raw, char* outp, int64_t u
 #pragma unroll
     for (int j = 0; j < U; ++j) d[j] += (off == (uint64_t)j) ? gi : 0.0f;
   }
-  store_unit<DTO, U>(outp, unit, d);
+  store_unit<DTO, U, NTS>(outp, unit, d);
 }
 
 }  // namespace prl
