@@ -844,7 +844,9 @@ __global__ __launch_bounds__(256) void k_swiglu_rows_fwd(const char* __restrict_
   constexpr int VE = DT == PRL_F32 ? 4 : 8;
   const int64_t nvec = rows * row_vecs;
   for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
-    const int64_t row = v / row_vecs, cv = v - row * row_vecs;
+    // (32-bit division where it fits: a 64-bit one costs a few dozen instructions per vector)
+    const int64_t row = nvec < ((int64_t)1 << 31) ? (int64_t)((uint32_t)v / (uint32_t)row_vecs) : v / row_vecs;
+    const int64_t cv = v - row * row_vecs;
     float g[VE], u[VE], o[VE];
     load_vec<DT>(gate + row * in_pitch, cv, g);
     load_vec<DT>(up + row * in_pitch, cv, u);
@@ -863,7 +865,8 @@ __global__ __launch_bounds__(256) void k_swiglu_rows_bwd(const char* __restrict_
   constexpr int VE = DT == PRL_F32 ? 4 : 8;
   const int64_t nvec = rows * row_vecs;
   for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
-    const int64_t row = v / row_vecs, cv = v - row * row_vecs;
+    const int64_t row = nvec < ((int64_t)1 << 31) ? (int64_t)((uint32_t)v / (uint32_t)row_vecs) : v / row_vecs;
+    const int64_t cv = v - row * row_vecs;
     float g[VE], u[VE], d[VE], dg[VE], du[VE];
     load_vec<DT>(gate + row * in_pitch, cv, g);
     load_vec<DT>(up + row * in_pitch, cv, u);
@@ -880,6 +883,10 @@ __global__ __launch_bounds__(256) void k_swiglu_rows_bwd(const char* __restrict_
 }
 
 }  // namespace prl
+
+// One vector per thread and exit wherever the grid allows it: short-lived waves sweep the operands front to back,
+// which streams faster than a capped grid striding over them (6.5 against 5.6-5.8 TB/s for a plain copy).
+static constexpr int64_t kSwigluGridCap = (int64_t)1 << 30;
 
 static int swiglu_check(const char* who, int dtype, int64_t n, const void* a, const void* b, const void* c) {
   if (dtype != PRL_F32 && dtype != PRL_BF16) {
@@ -900,7 +907,7 @@ extern "C" int prl_swiglu_fwd(const void* gate, const void* up, void* out, int d
   if (rc != PRL_OK || n == 0) return rc;
   const int64_t nvec = n / (dtype == PRL_F32 ? 4 : 8);
   const int64_t want = (nvec + 255) / 256;
-  const dim3 grid((unsigned)(want < 8192 ? want : 8192));
+  const dim3 grid((unsigned)(want < kSwigluGridCap ? want : kSwigluGridCap));
   if (dtype == PRL_BF16)
     hipLaunchKernelGGL((prl::k_swiglu_fwd<PRL_BF16>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)gate,
                        (const char*)up, (char*)out, nvec);
@@ -920,7 +927,7 @@ extern "C" int prl_swiglu_bwd(const void* gate, const void* up, const void* gout
   if (rc != PRL_OK || n == 0) return rc;
   const int64_t nvec = n / (dtype == PRL_F32 ? 4 : 8);
   const int64_t want = (nvec + 255) / 256;
-  const dim3 grid((unsigned)(want < 8192 ? want : 8192));
+  const dim3 grid((unsigned)(want < kSwigluGridCap ? want : kSwigluGridCap));
   if (dtype == PRL_BF16)
     hipLaunchKernelGGL((prl::k_swiglu_bwd<PRL_BF16>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)gate,
                        (const char*)up, (const char*)gout, (char*)ggate, (char*)gup, nvec);
@@ -957,7 +964,7 @@ extern "C" int prl_swiglu_rows_fwd(const void* gate, const void* up, int64_t in_
   if (rc != PRL_OK || rows * cols == 0) return rc;
   const int es = dtype == PRL_F32 ? 4 : 2;
   const int64_t row_vecs = cols * es / 16, want = (rows * row_vecs + 255) / 256;
-  const dim3 grid((unsigned)(want < 8192 ? want : 8192));
+  const dim3 grid((unsigned)(want < kSwigluGridCap ? want : kSwigluGridCap));
   if (dtype == PRL_BF16)
     hipLaunchKernelGGL((prl::k_swiglu_rows_fwd<PRL_BF16>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)gate,
                        (const char*)up, in_pitch * es, (char*)out, out_pitch * es, rows, row_vecs);
@@ -978,7 +985,7 @@ extern "C" int prl_swiglu_rows_bwd(const void* gate, const void* up, int64_t in_
   if (rc != PRL_OK || rows * cols == 0) return rc;
   const int es = dtype == PRL_F32 ? 4 : 2;
   const int64_t row_vecs = cols * es / 16, want = (rows * row_vecs + 255) / 256;
-  const dim3 grid((unsigned)(want < 8192 ? want : 8192));
+  const dim3 grid((unsigned)(want < kSwigluGridCap ? want : kSwigluGridCap));
   if (dtype == PRL_BF16)
     hipLaunchKernelGGL((prl::k_swiglu_rows_bwd<PRL_BF16>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)gate,
                        (const char*)up, in_pitch * es, (const char*)gout, gout_pitch * es, (char*)ggate, (char*)gup,
