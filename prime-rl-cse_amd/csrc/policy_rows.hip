@@ -127,6 +127,8 @@ __global__ __launch_bounds__(kRowThreads) void k_policy_rows(
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
 #if PRL_ROWS_XCD_BLOCKS
   // workgroups go to the XCDs round-robin (workgroup b runs on XCD b % 8); gridDim.x is a multiple of 8
+  // (Every XCD starting its eighth at another place, so that the rows the eight XCDs work on at a time do not lie a
+  // multiple of 64 KB apart, changes nothing: 222.1-222.5 against 220.4-221.2 us.)
   const int64_t row = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
 #else
   const int64_t row = blockIdx.x;  // row of the logits and of the gradient
