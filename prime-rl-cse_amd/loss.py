@@ -369,7 +369,7 @@ class _PolicyLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, logits, input_ids, position_ids, advantages, old_logprobs, loss_mask, temperature,
-                loss_config, loss_scale, skip_masked, positions=None):
+                loss_config, loss_scale, skip_masked, positions=None, max_sample_len=None):
         dev = C.require_device(logits, input_ids, position_ids, advantages, old_logprobs, loss_mask)
         lib = C.load()
         logits = _rows(logits)
@@ -407,6 +407,11 @@ class _PolicyLoss(torch.autograd.Function):
             raise ValueError("policy_loss: gathered rows (`positions`) need ratio_type 'token', bf16 logits that "
                              "require a gradient, a vocabulary that is a multiple of 8 and at most 155648, and T > 0")
         seq_limits = _seq_rows_limits() if per_seq else None
+        if seq_limits is not None and max_sample_len is not None and int(max_sample_len) > seq_limits[0]:
+            # a sample too long for its workgroups to wait for each other: its rows would all be left to the second
+            # pass, after the one-pass kernel has read them for nothing; two passes from the start are faster then
+            # (and with a fifth of the rows left over the two passes already win)
+            seq_limits = None
         seq_pass = (
             per_seq and seq_limits is not None and t > 0 and ctx.needs_input_grad[0] and _rows_kernel_enabled()
             and logits.data_ptr() % 16 == 0
@@ -530,7 +535,7 @@ class _PolicyLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_loss, *_):
         if grad_loss is None:
-            return (None,) * 11
+            return (None,) * 12
         gscale = grad_loss.to(torch.float32).reshape(1).contiguous()
         if ctx.single_pass:
             d = ctx.dlogits
@@ -541,7 +546,7 @@ class _PolicyLoss(torch.autograd.Function):
             dev = d.device
             unit = _UNIT_GRADIENTS.get(dev)
             if unit is not None and grad_loss.data_ptr() == unit.data_ptr():
-                return (d,) + (None,) * 10  # the caller passed unit_gradient(): known to be 1
+                return (d,) + (None,) * 11  # the caller passed unit_gradient(): known to be 1
             _, t, v = d.shape
             with C.on_device(dev), C.timed("prl_scale_rows_if_not_one", dev):
                 C.check(
@@ -549,10 +554,10 @@ class _PolicyLoss(torch.autograd.Function):
                                                        C.stream_ptr(dev)),
                     "prl_scale_rows_if_not_one",
                 )
-            return (d,) + (None,) * 10
+            return (d,) + (None,) * 11
         logits, ids, lse, g = ctx.saved_tensors
         d = _launch_bwd(logits, ids, lse, g, gscale, ctx.temperature, True)
-        return (d,) + (None,) * 10
+        return (d,) + (None,) * 11
 
 
 def policy_loss(
@@ -567,6 +572,7 @@ def policy_loss(
     loss_scale: float,
     skip_masked: bool = False,
     positions: Tensor | None = None,
+    max_sample_len: int | None = None,
 ) -> tuple[Tensor, dict[str, Tensor]]:
     """One micro-batch of the trainer's hot loop from the model's logits to a
     differentiable loss (src/prime_rl/trainer/rl/train.py:285-303) in one call
@@ -588,6 +594,11 @@ def policy_loss(
     inside the launch (rows of samples longer than ~224 tokens, and rows whose wait ran out, take a second pass
     over those rows only).  In every other case `.backward()` runs one more pass over the logits.
 
+    `max_sample_len` (sequence mode only, optional): the longest sample of the row if the caller knows it from the
+    host side (the trainers do, from the row's position ids before they are copied to the device).  A row with a
+    sample of more than ~224 tokens goes through the two passes at once instead of trying the one-pass kernel
+    first (308 against 348 us at the benchmark shape); without the hint the one-pass kernel is tried.
+
     `positions` (int64 [R], on the device): the logits are GATHERED rows, [1, R, V]: the LM head was run only at
     these positions of the packed row (`scored_positions` picks the ones whose next token is scored), row r
     predicting token positions[r] + 1.  Everything per token still has T entries; tokens that no row predicts
@@ -598,7 +609,7 @@ def policy_loss(
         raise ValueError(f"policy_loss takes one packed row, logits [1, T, V]; got {tuple(logits.shape)}")
     loss, lp, ent, ratio, clipped, is_clipped, seg_start, n_seg = _PolicyLoss.apply(
         logits, input_ids, position_ids, advantages, old_logprobs, loss_mask, float(temperature), loss_config,
-        float(loss_scale), bool(skip_masked), positions,
+        float(loss_scale), bool(skip_masked), positions, max_sample_len,
     )
     return loss, {
         "logprobs": lp,

@@ -433,7 +433,7 @@ class Replica:
         # normaliser 1 here: the step's own normaliser multiplies the gradients when they are accumulated
         loss, aux = policy_loss(logits, mb["input_ids"], mb["position_ids"], mb["advantages"], mb["logprobs"],
                                 mb["loss_mask"], mb["temperature"], loss_config, 1.0, skip_masked=True,
-                                positions=keep)
+                                positions=keep, max_sample_len=None if plan is None else plan.lmax)
         del logits
         loss.backward(unit_gradient(self.device))
         grads = [p.grad for p in self.state.params]

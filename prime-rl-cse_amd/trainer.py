@@ -530,7 +530,7 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, micro_batches
             vocab = int(logits.shape[-1])
             loss, aux = policy_loss(logits, mb["input_ids"], mb["position_ids"], mb["advantages"], mb["logprobs"],
                                     mb["loss_mask"], mb["temperature"], loss_config, loss_scale, skip_masked=True,
-                                    positions=keep)
+                                    positions=keep, max_sample_len=None if plan is None else plan.lmax)
             del logits
             loss.backward(unit_gradient(loss.device))
         if rows is not None:

@@ -419,3 +419,26 @@ def test_sequence_rows_kernel_beside_other_work_on_the_gpu():
         close(ratio[:n], want["importance_ratio"])
         assert bf16_ulp_close(d.cpu(), want["dlogits"][0], ulps=1, atol=1e-9)
     print("rows left to the second pass beside a busy stream, by wait length:", seen)
+
+
+def test_sequence_mode_with_a_long_sample_announced_takes_the_two_passes():
+    """`max_sample_len` beyond what workgroups wait for: `policy_loss` does not try the one-pass kernel (whose rows
+    would all be left to the second pass); results are the oracle's either way."""
+    from prime_rl_cse_amd import loss as L
+
+    lengths = [300, 40, 72]
+    vocab = 32768
+    logits, ids, pos, mask, adv, old = seeded_case(29, lengths, 0, vocab, 1.0, mask_p=0.8)
+    cfg = prl.LossConfig(ratio_type="sequence", ratio_length_norm=True, clip_ratio=1.2)
+    b = lambda x: x.unsqueeze(0)
+    want = O.policy_epilogue(logits, b(ids), b(pos), b(adv), b(old), b(mask), 1.0, cfg, len(lengths))
+    for hint, one_pass in ((300, False), (None, True), (200, True)):
+        L._LAST_SEQ_PENDING[0] = None
+        dl = logits.to(DEV).requires_grad_(True)
+        loss, aux = prl.policy_loss(dl, b(ids).to(DEV), b(pos).to(DEV), b(adv).to(DEV), b(old).to(DEV),
+                                    b(mask).to(DEV), 1.0, cfg, len(lengths), max_sample_len=hint)
+        loss.backward()
+        assert (L._LAST_SEQ_PENDING[0] is not None) == one_pass
+        close(loss, want["loss"])
+        close(aux["importance_ratio"][: len(lengths)], want["importance_ratio"])
+        assert bf16_ulp_close(dl.grad.cpu(), want["dlogits"], ulps=1, atol=1e-9)
