@@ -20,7 +20,7 @@ __global__ __launch_bounds__(THREADS) void k_fill_stride(u32x4* __restrict__ out
   }
 }
 // a row per workgroup of 1024 threads; ORDER: which 1 KB block of the row wave w writes in round j
-//  0: j * 16 + w (16 KB contiguous per round)   1: w * 19 + j (a wave owns 19 KB)   2: j + 19 * w (blocks of a round 19 KB apart)
+//  0: j * 16 + w (16 KB contiguous per round)   1: w * 19 + j (a wave owns 19 KB)   2: j + 19 * w (the blocks of one pass lie 19 KB apart)
 //  3: rounds in reverse   4: round order rotated by the row index (rows of neighbouring units start at different offsets)
 template <int ORDER>
 __global__ __launch_bounds__(1024) void k_row(u32x4* __restrict__ out, long rows) {
