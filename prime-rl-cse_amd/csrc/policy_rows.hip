@@ -140,7 +140,8 @@ __global__ __launch_bounds__(kRowThreads) void k_policy_rows(
   // The token this row predicts.  Whole packed row: row r holds the logits at position r (n_rows == T).  Gathered
   // rows (`positions` given): row r holds the logits the model produced at position positions[r] of a packed row
   // of T tokens; token 0 and the tokens no row predicts are the caller's business.
-  const int64_t t = positions ? positions[row] + 1 : row + 1;
+  const int64_t at = positions ? positions[row] : row;  // position of the packed row this row of logits belongs to
+  const int64_t t = (int64_t)((uint64_t)at + 1u);       // (not used when `at` is out of range, see below)
   const int nchunk = (int)(V >> 3);
   const float c2 = inv_temp * kLog2e;
 
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(kRowThreads) void k_policy_rows(
     for (int j = 0; j < NCH; ++j) store_chunk(z, out_rsrc, lane_off, j * kSlab);
   };
 
-  if (positions && (t < 1 || t >= T)) {  // a position outside the packed row: nothing is read, nothing is emitted
+  if (positions && (at < 0 || at >= T - 1)) {  // a position outside the packed row: nothing is read, nothing is emitted
     zero_row();
     return;
   }
