@@ -509,6 +509,9 @@ def main(argv: list[str] | None = None) -> int:
                            "micro_batch": info["micro_batch_size"], "parallelism": f"dp{world}"},
                 "trainer_step": info}), file=LINE_OUT, flush=True)
         return 0
+    if backend == "nccl" and local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local}, but this process sees {torch.cuda.device_count()} "
+                         f"(--gpus {args.gpus} needs one GPU per rank; PRL_BENCH_BACKEND=gloo shares GPUs for rehearsals)")
     local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
