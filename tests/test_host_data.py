@@ -167,3 +167,42 @@ def test_scored_positions_are_the_positions_whose_next_token_is_scored():
     assert prl.scored_positions(mask, multiple=16).tolist() == list(range(7))
     assert prl.scored_positions(torch.zeros(1, 5, dtype=torch.bool), multiple=4).numel() == 0
     assert prl.scored_positions(mask, multiple=3).tolist() == [1, 2, 5]
+
+
+def test_scored_rows_engage_only_where_they_apply(monkeypatch):
+    """`trainer.scored_rows` (host logic): token mode, a model computing bf16 logits over a vocabulary the row
+    kernel takes, and at most 0.9 of a row's positions left after rounding up to a multiple of 256."""
+    import types
+
+    import prime_rl_cse_amd as prl
+    from prime_rl_cse_amd import trainer as T
+
+    def model(dtype, vocab):
+        m = torch.nn.Linear(2, 2).to(dtype)
+        m.config = types.SimpleNamespace(vocab_size=vocab)
+        return m
+
+    t = 2048
+    mask = torch.zeros(1, t, dtype=torch.bool)
+    mask[0, 600:1500] = True  # 900 scored tokens
+    mb = {"loss_mask": mask}
+    tok, seq = prl.LossConfig(), prl.LossConfig(ratio_type="sequence")
+    keep = T.scored_rows(mb, tok, model(torch.bfloat16, 151936), "cpu")
+    assert keep is not None and keep.numel() == 1024 and keep.dtype == torch.int64
+    assert set(range(599, 1499)) <= set(keep.tolist())  # position p feeds token p + 1
+    assert T.scored_rows(mb, seq, model(torch.bfloat16, 151936), "cpu") is None
+    assert T.scored_rows(mb, tok, model(torch.float32, 151936), "cpu") is None
+    assert T.scored_rows(mb, tok, model(torch.bfloat16, 151937), "cpu") is None  # not a multiple of 8
+    assert T.scored_rows(mb, tok, model(torch.bfloat16, 200000), "cpu") is None  # wider than a row's registers
+    fsdp_like = model(torch.float32, 151936)
+    fsdp_like._prl_compute_dtype = torch.bfloat16  # fp32 parameters, bf16 compute: what `setup_fsdp` records
+    assert T.scored_rows(mb, tok, fsdp_like, "cpu").numel() == 1024
+    dense = {"loss_mask": torch.ones(1, t, dtype=torch.bool)}
+    assert T.scored_rows(dense, tok, model(torch.bfloat16, 151936), "cpu") is None
+    nearly = {"loss_mask": torch.rand(1, t, generator=torch.Generator().manual_seed(0)) < 0.89}
+    assert T.scored_rows(nearly, tok, model(torch.bfloat16, 151936), "cpu") is None  # ~1820, rounded up: over 0.9 of 2047
+    most = {"loss_mask": torch.rand(1, t, generator=torch.Generator().manual_seed(0)) < 0.8}
+    assert T.scored_rows(most, tok, model(torch.bfloat16, 151936), "cpu").numel() == 1792  # ~1640 -> 1792 of 2047
+    assert T.scored_rows({"loss_mask": torch.zeros(1, t, dtype=torch.bool)}, tok, model(torch.bfloat16, 151936), "cpu") is None
+    monkeypatch.setenv("PRL_GATHER_SCORED", "0")
+    assert T.scored_rows(mb, tok, model(torch.bfloat16, 151936), "cpu") is None
