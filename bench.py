@@ -70,6 +70,9 @@ def parse(argv: list[str] | None = None) -> argparse.Namespace:
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of the baseline sample")
     p.add_argument("--no-stats", action="store_true", help="leave the logged statistics out of the step")
+    p.add_argument("--event-pairs", action="store_true",
+                   help="time the dominant kernel with an event recorded on either side of its call instead of with "
+                        "events stamped by the launch itself")
     p.add_argument("--workload", choices=["epilogue", "trainer"], default="epilogue",
                    help="epilogue: the hot path from resident logits (the headline line); trainer: the whole "
                         "optimizer step with a random-init Qwen3-0.6B body under FSDP2")
@@ -557,7 +560,12 @@ def main(argv: list[str] | None = None) -> int:
     # microseconds of queue time); the other kernels are timed in a short untimed pass afterwards
     # ... and of its launches one in seven (with 8 per step, a sample that walks over all 8 rows; an event pair
     # holds the queue up for ~11 us, which at one in three was 1.6 % of the step)
-    timer = _capi.KernelTimer(only={"prl_logprob_bwd", "prl_policy_rows_fwd_bwd"}, every=7)
+    # The single-pass kernel is timed by its own start and end on the GPU (events the launch itself stamps:
+    # the duration a profiler's kernel trace shows); --event-pairs records an event on either side of the call
+    # instead, which is also how the two-pass backward is timed.
+    stamps = 0 if args.event_pairs else args.steps * len(rows) // 7 + 2
+    timer = _capi.KernelTimer(only={"prl_logprob_bwd", "prl_policy_rows_fwd_bwd"}, every=7, kernel_stamps=stamps,
+                              device=dev)
     _capi.set_timer(timer)
     if world > 1:
         dist.barrier()
@@ -656,6 +664,9 @@ def main(argv: list[str] | None = None) -> int:
                 "bytes_per_launch": dom_bytes,
                 "mean_ms": dom["mean_ms"],
                 "launches": dom["launches"],
+                "timed_by": ("HIP events stamped by the kernel launch itself (hipExtLaunchKernelGGL), one launch in seven"
+                             if single_pass and not args.event_pairs else
+                             "HIP events recorded on the launch stream before and after the call, one launch in seven"),
             },
             "kernels": {
                 dom_call: {"mean_ms": dom["mean_ms"], "GBps": achieved},

@@ -236,6 +236,15 @@ int prl_policy_rows_fwd_bwd(const void* logits, int logits_dtype, int64_t T, int
                             void* stream);
 
 /*
+ * Measurement aid, no counterpart in the reference: the NEXT prl_policy_rows_fwd_bwd call made from this thread
+ * stamps the two HIP events (hipEvent_t, created by the caller with timing enabled) with the start and the end of its
+ * row kernel on the GPU (the launch goes through hipExtLaunchKernelGGL), so that hipEventElapsedTime(start, stop) is
+ * the kernel's own duration: what a profiler's kernel trace reports, without an event record on either side of the
+ * launch holding the queue up.  One launch per request; two NULLs take a request back.
+ */
+int prl_policy_rows_time_next(void* start_event, void* stop_event);
+
+/*
  * prl_policy_rows_fwd_bwd over GATHERED rows: the model's LM head was run only at the positions whose next token
  * is scored, so `logits` holds R rows, row r being the logits at position positions[r] of a packed row of T tokens
  * (it predicts token positions[r] + 1).  With prompts masked out of the loss (src/prime_rl/orchestrator/batch.py:21-62

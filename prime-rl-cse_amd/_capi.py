@@ -84,6 +84,7 @@ SIGNATURES = {
         [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float,
          c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p],
     ),
+    "prl_policy_rows_time_next": (c_int, [c_void_p, c_void_p]),
     "prl_policy_rows_gathered_fwd_bwd": (
         c_int,
         [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
@@ -284,11 +285,26 @@ class KernelTimer:
     to (torch's current stream).  Meant for benchmarks: install one with
     `set_timer`, run, synchronise, read `summary()`."""
 
-    def __init__(self, only: set[str] | None = None, every: int = 1):
+    def __init__(self, only: set[str] | None = None, every: int = 1, kernel_stamps: int = 0,
+                 device: torch.device | None = None):
+        """`kernel_stamps` > 0: launches of prl_policy_rows_fwd_bwd are timed by the kernel's own start and end on
+        the GPU (`prl_policy_rows_time_next`) instead of by an event recorded on either side of the call; that
+        many pairs of events are made ready here, on `device`, outside any timed region (an event exists only
+        once it has been recorded)."""
         self.events: dict[str, list[tuple[torch.cuda.Event, torch.cuda.Event]]] = {}
         self.only = only  # names to time; None = every named launch
         self.every = max(int(every), 1)  # time one launch in `every` (an event pair drains the queue around it)
         self._seen: dict[str, int] = {}
+        self._stamps: list[tuple[torch.cuda.Event, torch.cuda.Event]] = []
+        if kernel_stamps > 0:
+            dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+            st = torch.cuda.current_stream(dev)
+            for _ in range(kernel_stamps):
+                pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                pair[0].record(st)
+                pair[1].record(st)
+                self._stamps.append(pair)
+            st.synchronize()
 
     def span(self, name: str, device: torch.device):
         if self.only is not None and name not in self.only:
@@ -297,6 +313,8 @@ class KernelTimer:
         self._seen[name] = n + 1
         if n % self.every:
             return _no_span
+        if name == "prl_policy_rows_fwd_bwd" and self._stamps:
+            return _StampSpan(self, name, self._stamps.pop())
         return _Span(self, name, device)
 
     def summary(self) -> dict[str, dict[str, float]]:
@@ -319,6 +337,23 @@ class _Span:
     def __exit__(self, *exc):
         self.stop.record(torch.cuda.current_stream(self.device))
         self.timer.events.setdefault(self.name, []).append((self.start, self.stop))
+        return False
+
+
+class _StampSpan:
+    """The row kernel's own start and end: the two events are handed to the library, which attaches them to the
+    launch the enclosed call makes."""
+
+    def __init__(self, timer: KernelTimer, name: str, pair: tuple[torch.cuda.Event, torch.cuda.Event]):
+        self.timer, self.name, self.pair = timer, name, pair
+
+    def __enter__(self):
+        check(load().prl_policy_rows_time_next(c_void_p(self.pair[0].cuda_event), c_void_p(self.pair[1].cuda_event)),
+              "prl_policy_rows_time_next")
+
+    def __exit__(self, *exc):
+        load().prl_policy_rows_time_next(None, None)  # (already taken by the launch; cleared if the call failed)
+        self.timer.events.setdefault(self.name, []).append(self.pair)
         return False
 
 

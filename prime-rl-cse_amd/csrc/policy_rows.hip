@@ -24,6 +24,8 @@
 // known, and fp32 rows do not fit the registers: both take the two-kernel path.
 #include <type_traits>
 
+#include <hip/hip_ext.h>
+
 #include "logprob_dev.h"
 
 // Build-time tunables (defaults = measured best on MI355X; tools/tune_rows.py builds and compares variants)
@@ -1135,6 +1137,19 @@ int segments_impl(const int64_t* pos, int64_t T, int32_t* seg_id, int64_t* seg_s
 
 using namespace prl;
 
+// Events for the next launch of the row kernel from this thread (prl_policy_rows_time_next): the launch then goes
+// through hipExtLaunchKernelGGL, which stamps the two events with the kernel's own start and end on the GPU.
+static thread_local hipEvent_t g_time_start = nullptr, g_time_stop = nullptr;
+
+extern "C" int prl_policy_rows_time_next(void* start_event, void* stop_event) {
+  clear_error();
+  PRL_REQUIRE((start_event == nullptr) == (stop_event == nullptr),
+              "policy_rows_time_next: pass two events, or two NULLs to take the request back");
+  g_time_start = (hipEvent_t)start_event;
+  g_time_stop = (hipEvent_t)stop_event;
+  return PRL_OK;
+}
+
 extern "C" int prl_policy_rows_supported(int logits_dtype, int64_t T, int64_t V, int64_t row_stride, int out_dtype,
                                          int64_t out_row_stride) {
   if (logits_dtype != PRL_BF16 || out_dtype != PRL_BF16) return 0;
@@ -1189,10 +1204,17 @@ extern "C" int prl_policy_rows_fwd_bwd(const void* logits, int logits_dtype, int
                      old, adv, mask_words, mask_mis, skip_masked ? 1 : 0, inv_temp, clip_ratio, 1.0f / scale,     \
                      logprob, entropy, lse, (char*)dlogits, out_row_stride * 2)
 #else
+#define PRL_ROWS_ARGS                                                                                              \
+  (const char*)logits, T, V, (int64_t)(row_stride * 2), ids, old, adv, mask_words, mask_mis, (int)(skip_masked ? 1 : 0), \
+      inv_temp, clip_ratio, (float)(1.0f / scale), logprob, entropy, lse, (char*)dlogits, (int64_t)(out_row_stride * 2), \
+      (const int64_t*)nullptr, T
 #define PRL_ROWS(N)                                                                                                \
-  hipLaunchKernelGGL((k_policy_rows<N>), grid, block, 0, st, (const char*)logits, T, V, row_stride * 2, ids, old, \
-                     adv, mask_words, mask_mis, skip_masked ? 1 : 0, inv_temp, clip_ratio, 1.0f / scale, logprob, entropy, lse,   \
-                     (char*)dlogits, out_row_stride * 2, (const int64_t*)nullptr, T)
+  do {                                                                                                             \
+    if (g_time_start && g_time_stop)                                                                               \
+      hipExtLaunchKernelGGL((k_policy_rows<N>), grid, block, 0, st, g_time_start, g_time_stop, 0, PRL_ROWS_ARGS);  \
+    else                                                                                                           \
+      hipLaunchKernelGGL((k_policy_rows<N>), grid, block, 0, st, PRL_ROWS_ARGS);                                   \
+  } while (0)
 #endif
   // sizes at most kTailSlabs = 4 apart, so that the row always ends in the last 4 slabs of its kernel
   if (need <= 2)
@@ -1208,6 +1230,10 @@ extern "C" int prl_policy_rows_fwd_bwd(const void* logits, int logits_dtype, int
   else
     PRL_ROWS(19);
 #undef PRL_ROWS
+#ifdef PRL_ROWS_ARGS
+#undef PRL_ROWS_ARGS
+#endif
+  g_time_start = g_time_stop = nullptr;  // one launch per request
   PRL_CHECK_LAUNCH("policy_rows_fwd_bwd");
   return PRL_OK;
 }

@@ -442,3 +442,30 @@ def test_sequence_mode_with_a_long_sample_announced_takes_the_two_passes():
         close(loss, want["loss"])
         close(aux["importance_ratio"][: len(lengths)], want["importance_ratio"])
         assert bf16_ulp_close(dl.grad.cpu(), want["dlogits"], ulps=1, atol=1e-9)
+
+
+def test_kernel_stamped_timing_of_the_row_kernel():
+    """`prl_policy_rows_time_next`: the next launch stamps two events with the kernel's own start and end; results
+    are those of an ordinary launch, the request is spent by one launch, and the time is a plausible kernel time
+    (below what events recorded around the call see)."""
+    lib = C.load()
+    logits, ids, pos, mask, adv, old = seeded_case(3, [64] * 8, 0, 32768, 1.0, mask_p=1.0)
+    t = ids.numel()
+    x = logits[0].to(DEV)
+    args = (x, ids.to(DEV), adv.to(DEV), old.to(DEV), mask.to(torch.uint8).to(DEV), 1.0, 8.0, t, False)
+    plain = rows_call(*args)
+    timer = C.KernelTimer(kernel_stamps=2, device=torch.device(DEV))
+    (a, b), (c, d) = timer._stamps
+    C.check(lib.prl_policy_rows_time_next(C.c_void_p(a.cuda_event), C.c_void_p(b.cuda_event)), "time_next")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    stamped = rows_call(*args)
+    e1.record()
+    again = rows_call(*args)  # no request pending any more: an ordinary launch
+    torch.cuda.synchronize()
+    for u, v, w in zip(plain, stamped, again):
+        assert torch.equal(u, v) and torch.equal(u, w)
+    kernel_ms, around_ms = a.elapsed_time(b), e0.elapsed_time(e1)
+    assert 0.0 < kernel_ms < around_ms, (kernel_ms, around_ms)
+    with pytest.raises(RuntimeError, match="two events"):
+        C.check(lib.prl_policy_rows_time_next(C.c_void_p(c.cuda_event), None), "time_next")
