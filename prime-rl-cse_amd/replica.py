@@ -701,28 +701,82 @@ class Replica:
         same results and the same `StepResult` as `trainer.train_step`, micro-batches joined the same way and
         fillers left out the same way (`trainer.scored`)."""
         from .trainer import (MERGE_MAX_TOKENS, StepResult, attention_plan, join_micro_batches, join_per_row,
-                              add_ratio_statistics, local_loss_scale, ones_as_recomputed_error, restore_row_starts,
-                              scored, scored_rows)
+                              add_ratio_statistics, forward, local_loss_scale, losses_per_given_row,
+                              ones_as_recomputed_error, restore_row_starts, scored, scored_rows, split_by_gradient)
 
         join_tokens = MERGE_MAX_TOKENS if join_tokens is None else join_tokens
         t0 = time.perf_counter()
         n_given = len(micro_batches)
         inv_scale = 1.0 / max(float(local_loss_scale(micro_batches, loss_config)), 1.0)
         self._starts_sums = not self.graphs
-        if skip_unscored and loss_config.ratio_type == "token":
+        token_mode = loss_config.ratio_type == "token"
+        given_row = list(range(n_given))  # the given row every micro-batch still in the list came from
+        if skip_unscored and token_mode:
             keep = scored(micro_batches)
             micro_batches = [micro_batches[i] for i in keep]
+            given_row = keep
             if recomputed_errors is not None:
                 recomputed_errors = [recomputed_errors[i] for i in keep]
+        # samples nothing can be learned from (advantage 0 wherever they are scored) take a forward pass only
+        forward_only: list[MicroBatch] = []
+        forward_row: list[int] = []
+        if skip_unscored and token_mode and recomputed_errors is None and not self.graphs:
+            split = split_by_gradient(micro_batches)
+            if split is not None:
+                micro_batches, rows_a, forward_only, rows_b = split
+                forward_row = [given_row[i] for i in rows_b]
+                given_row = [given_row[i] for i in rows_a]
         self._scale.fill_(inv_scale)
         tensors = Tensors()
-        tokens = 0
-        rows = join_micro_batches(micro_batches, join_tokens) if loss_config.ratio_type == "token" and join_tokens > 0 \
-            else None
-        units = [r.micro_batch for r in rows] if rows is not None else micro_batches
+        vocab = int(self.model.config.vocab_size)
+        loss_parts: list[Tensor] = []
+        loss_rows: list[int] = []
+        state = {"tokens": 0, "passes": 0}
+
+        def units_of(mbs: list[MicroBatch]) -> tuple[list[Any] | None, list[MicroBatch]]:
+            rows = join_micro_batches(mbs, join_tokens) if token_mode and join_tokens > 0 else None
+            return rows, ([r.micro_batch for r in rows] if rows is not None else mbs)
+
+        def book(joined: Any, mb: dict[str, Any], loss: Tensor, aux: dict[str, Tensor], came_from: list[int],
+                 error: Tensor | None) -> None:
+            """Statistics and per-row losses of one pass (many small launches: after the pass's own work)."""
+            if joined is not None:
+                losses = restore_row_starts(joined, mb, aux, loss_config, vocab, inv_scale)
+                mask = host_to_device(joined.loss_mask, self.device)
+            else:
+                losses, mask = (loss * inv_scale).reshape(1), mb["loss_mask"]
+            tensors.add("probs", aux["logprobs"], mask, exp=True)
+            tensors.add("old_probs", mb["logprobs"], mask, exp=True)
+            tensors.add("entropy", aux["entropy"], mask)
+            loss_parts.append(losses)
+            loss_rows.extend(came_from)
+            if error is not None:
+                tensors.add("recomputed_logprob_error", error, mask)
+            add_ratio_statistics(tensors, aux, mask, loss_config)
+            state["tokens"] += int(mb["input_ids"].numel()) - (joined.padding if joined is not None else 0)
+            state["passes"] += 1
+
+        def pieces_of(rows: list[Any] | None, k: int, came_from: list[int]) -> tuple[list[int], int]:
+            n = len(rows[k].lengths) if rows is not None else 1
+            at = sum(len(r.lengths) for r in rows[:k]) if rows is not None else k
+            return came_from[at : at + n], n
+
+        # forward only first, so that the last pass of the step is the one the exchange hangs on
+        rows_b, units_b = units_of(forward_only)
+        for k, host_mb in enumerate(units_b):
+            mb = to_device(host_mb, self.device)
+            plan = attention_plan(host_mb, self.device)
+            with torch.no_grad():
+                logits = forward(self.model, mb["input_ids"], mb["position_ids"], plan)
+                loss, aux = policy_loss(logits, mb["input_ids"], mb["position_ids"], mb["advantages"], mb["logprobs"],
+                                        mb["loss_mask"], mb["temperature"], loss_config, 1.0, skip_masked=True,
+                                        max_sample_len=None if plan is None else plan.lmax)
+                del logits
+            book(rows_b[k] if rows_b is not None else None, mb, loss, aux, pieces_of(rows_b, k, forward_row)[0], None)
+
+        rows, units = units_of(micro_batches)
         if rows is not None and recomputed_errors is not None:
             recomputed_errors = join_per_row(recomputed_errors, rows)
-        vocab = int(self.model.config.vocab_size)
         grad_norm = None
         for step_idx, host_mb in enumerate(units):
             mb = to_device(host_mb, self.device)
@@ -738,22 +792,11 @@ class Replica:
                 # while the host issues them, instead of the GPU waiting 0.3-0.5 ms for each in turn.
                 grad_norm = self.state.finish_step(self.optimizer, max_norm, keep_sums=not self.graphs,
                                                    gathers_in_flight=self.overlap)
-            if rows is not None:
-                losses = restore_row_starts(rows[step_idx], mb, aux, loss_config, vocab, inv_scale)
-                mask = host_to_device(rows[step_idx].loss_mask, self.device)
-            else:
-                losses, mask = (loss * inv_scale).reshape(1), mb["loss_mask"]
-            tensors.add("probs", aux["logprobs"], mask, exp=True)
-            tensors.add("old_probs", mb["logprobs"], mask, exp=True)
-            tensors.add("entropy", aux["entropy"], mask)
-            tensors.add("loss", losses)
-            if recomputed_errors is not None:
-                tensors.add("recomputed_logprob_error", recomputed_errors[step_idx], mask)
-            add_ratio_statistics(tensors, aux, mask, loss_config)
-            tokens += int(mb["input_ids"].numel()) - (rows[step_idx].padding if rows is not None else 0)
-        if n_given > len(micro_batches):  # every filler left out: a loss of 0, as the reference logs for it
-            tensors.add("loss", torch.zeros(n_given - len(micro_batches), dtype=torch.float32, device=self.device))
-        if not units:  # nothing was scored on this rank: its share of the mean is zero, not last step's sums
+            book(rows[step_idx] if rows is not None else None, mb, loss, aux, pieces_of(rows, step_idx, given_row)[0],
+                 recomputed_errors[step_idx] if recomputed_errors is not None else None)
+        # one loss per given micro-batch, as the reference logs it; 0 for those not run (nothing scored)
+        tensors.add("loss", losses_per_given_row(loss_parts, loss_rows, n_given, self.device))
+        if not units:  # nothing to learn from on this rank: its share of the mean is zero, not last step's sums
             self.state.acc32.zero_()
             grad_norm = self.state.finish_step(self.optimizer, max_norm, keep_sums=not self.graphs,
                                                gathers_in_flight=self.overlap)
@@ -766,7 +809,7 @@ class Replica:
         if samples is None:
             samples = n_given
         return StepResult(loss=stats.get("loss/mean", float("nan")), grad_norm=float(grad_norm), stats=stats,
-                          seconds=seconds, tokens=tokens, samples=samples, passes=len(units))
+                          seconds=seconds, tokens=state["tokens"], samples=samples, passes=state["passes"])
 
 
 def eligible(model: nn.Module, optim_type: str, activation_checkpointing: bool = False) -> str | None:

@@ -340,6 +340,110 @@ def scored_rows(host_micro_batch: MicroBatch, loss_config: LossConfig, model: nn
     return host_to_device(keep, device, torch.int64)
 
 
+def split_by_gradient(micro_batches: list[MicroBatch]
+                      ) -> tuple[list[MicroBatch], list[int], list[MicroBatch], list[int]] | None:
+    """The step's rows sorted into what needs a backward pass and what needs a forward pass only.
+
+    A token can only have a gradient if it is scored AND its advantage is not zero
+    (src/prime_rl/trainer/rl/loss.py:98-104: the loss term is -clipped_ratio * advantage under the mask).  With
+    group-relative advantages (src/prime_rl/orchestrator/advantage.py:18) every sample of a group whose rollouts
+    all earned the same reward has advantage 0, so whole samples contribute exact zeros to the loss and to every
+    gradient, and the reference still runs them through forward AND backward.  Their log-probabilities, entropies
+    and ratios are logged (train.py:313-333), so they need the forward pass, and nothing else: two thirds of their
+    cost goes away.
+
+    Returns (rows to train on, the given row each came from, rows for a forward pass only, the given row each came
+    from), or None when there is nothing to separate.  A row whose samples are all of one kind stays whole.  A
+    mixed row is cut into its samples (the attention's samples: position ids restart) only if no sample's first
+    token is scored: a first token is predicted from the token in front of it in the packed row
+    (loss.py:51-58), which moving the sample would change; prompts are masked out, so real rollouts qualify.
+    Samples without any scored token are dropped.  Host tensors only.
+
+    Worth it only where the passes are long enough to run at full rate either way: with 150 K tokens per step and
+    half of the problems settled a 0.6B step takes 0.43-0.54 s instead of 0.68-0.71 s, with 10 K tokens per step
+    (one short pass becoming two shorter ones, of lengths no product has met before) 0.051-0.058 s instead of
+    0.051-0.053 s.  So by default rows are separated only when at least `SPLIT_MIN_FORWARD_TOKENS` tokens go
+    forward-only out of at least `SPLIT_MIN_TOKENS`; PRL_SPLIT_NO_GRADIENT=1 separates always, =0 never."""
+    import os
+
+    import numpy as np
+
+    from .attention import sample_starts
+
+    mode = os.environ.get("PRL_SPLIT_NO_GRADIENT", "auto")
+    if mode == "0" or not micro_batches:
+        return None
+    if any(mb["loss_mask"].is_cuda or mb["loss_mask"].ndim != 2 or mb["loss_mask"].shape[0] != 1 for mb in micro_batches):
+        return None
+    grad: list[MicroBatch] = []
+    fwd: list[MicroBatch] = []
+    grad_row: list[int] = []
+    fwd_row: list[int] = []
+    changed = False
+
+    def piece(mb: MicroBatch, a: int, z: int) -> MicroBatch:
+        return {k: (v[:, a:z] if isinstance(v, Tensor) and v.ndim == 2 else v) for k, v in mb.items()}
+
+    for r, mb in enumerate(micro_batches):
+        mask = mb["loss_mask"][0].to(torch.bool)
+        live = mask & (mb["advantages"][0] != 0)  # (a NaN advantage counts: its NaN must reach the loss)
+        if not bool(mask.any()) or bool(live[mask].all()):  # nobody scored (the caller's business), or all live
+            grad.append(mb)
+            grad_row.append(r)
+            continue
+        if not bool(live.any()):  # scored, but nothing to learn from: the whole row forward only
+            fwd.append(mb)
+            fwd_row.append(r)
+            changed = True
+            continue
+        starts = sample_starts(mb["position_ids"])
+        n = int(mask.numel())
+        any_live = np.add.reduceat(live.numpy().astype(np.int64), starts) > 0
+        if bool(any_live.all()) or bool(mask[torch.from_numpy(starts)].any()):
+            grad.append(mb)  # every sample has live tokens, or a sample cannot be moved
+            grad_row.append(r)
+            continue
+        any_scored = np.add.reduceat(mask.numpy().astype(np.int64), starts) > 0
+        ends = np.append(starts[1:], n)
+        for a, z, lv, sc in zip(starts.tolist(), ends.tolist(), any_live.tolist(), any_scored.tolist()):
+            if lv:
+                grad.append(piece(mb, a, z))
+                grad_row.append(r)
+            elif sc:
+                fwd.append(piece(mb, a, z))
+                fwd_row.append(r)
+        changed = True
+    if not changed:
+        return None
+    if mode != "1":
+        moved = sum(int(mb["input_ids"].numel()) for mb in fwd)
+        total = moved + sum(int(mb["input_ids"].numel()) for mb in grad)
+        if moved < SPLIT_MIN_FORWARD_TOKENS or total < SPLIT_MIN_TOKENS:
+            return None
+    return grad, grad_row, fwd, fwd_row
+
+
+SPLIT_MIN_FORWARD_TOKENS = 4096  # `split_by_gradient`: fewer tokens than this are not worth a pass of their own
+SPLIT_MIN_TOKENS = 16384  # ... and a step shorter than this is one pass, which splitting would only make two of
+
+
+def losses_per_given_row(parts: list[Tensor], rows: list[int], n_given: int, device: torch.device | str) -> Tensor:
+    """The loss the reference logs per micro-batch (train.py:327-333) from the losses of the pieces the rows were
+    run as: `parts` concatenated has one entry per piece, `rows[i]` is the given row piece i came from.  Rows that
+    were not run at all (nothing scored) have loss 0.  Pieces of one row are added in the order they ran."""
+    out = torch.zeros(n_given, dtype=torch.float32, device=device)
+    if not rows:
+        return out
+    slot, seen = [], {}
+    for r in rows:
+        slot.append(seen.get(r, 0))
+        seen[r] = slot[-1] + 1
+    table = torch.zeros((n_given, max(seen.values())), dtype=torch.float32, device=device)
+    vals = torch.cat([p.reshape(-1).float() for p in parts])
+    table[host_to_device(rows, device, torch.int64), host_to_device(slot, device, torch.int64)] = vals
+    return table.sum(1)
+
+
 MERGE_MAX_TOKENS = 16384  # longest joined row (the one-launch loss kernel's limit, 5 GB of bf16 logits at V = 152 K)
 
 
@@ -488,7 +592,9 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, micro_batches
     micro-batches are joined into rows of up to `join_tokens` tokens and run as
     one (`join_micro_batches`; 0 keeps them apart).  Micro-batches without an
     unmasked token (the orchestrator's fillers) are not run in token mode where
-    that is this rank's own business (`scored`; `skip_unscored=False` runs them)."""
+    that is this rank's own business (`scored`; `skip_unscored=False` runs them),
+    and samples whose advantage is 0 wherever they are scored take a forward
+    pass only (`split_by_gradient`)."""
     t0 = time.perf_counter()
     n_given = len(micro_batches)
     loss_scale = local_loss_scale(micro_batches, loss_config)
@@ -500,17 +606,72 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, micro_batches
     # number of passes on every rank, so there the micro-batches stay apart.
     one_rank = not dist.is_initialized() or dist.get_world_size() == 1
     passes_are_local = one_rank or getattr(model, "_prl_keep_gathered", False) or not hasattr(model, "unshard")
-    left_out = 0
+    token_mode = loss_config.ratio_type == "token"
+    given_row = list(range(n_given))  # the given row every micro-batch still in the list came from
     # (token mode only: with one ratio per sample the reference logs every sample's ratio unmasked, a filler's too)
-    if passes_are_local and skip_unscored and loss_config.ratio_type == "token":
+    if passes_are_local and skip_unscored and token_mode:
         keep = scored(micro_batches)
-        left_out = len(micro_batches) - len(keep)
         micro_batches = [micro_batches[i] for i in keep]
+        given_row = keep
         if recomputed_errors is not None:
             recomputed_errors = [recomputed_errors[i] for i in keep]
-    rows = join_micro_batches(micro_batches, join_tokens) \
-        if loss_config.ratio_type == "token" and join_tokens > 0 and passes_are_local else None
-    units = [r.micro_batch for r in rows] if rows is not None else micro_batches
+    # samples nothing can be learned from (advantage 0 wherever they are scored) take a forward pass only
+    forward_only: list[MicroBatch] = []
+    forward_row: list[int] = []
+    if passes_are_local and skip_unscored and token_mode and recomputed_errors is None:
+        split = split_by_gradient(micro_batches)
+        if split is not None:
+            micro_batches, rows_a, forward_only, rows_b = split
+            forward_row = [given_row[i] for i in rows_b]
+            given_row = [given_row[i] for i in rows_a]
+    inv_scale = 1.0 / max(float(loss_scale), 1.0)
+    loss_parts: list[Tensor] = []
+    loss_rows: list[int] = []
+    passes = 0
+    vocab = int(getattr(getattr(model, "config", None), "vocab_size", 0))
+
+    def units_of(mbs: list[MicroBatch]) -> tuple[list[JoinedRows] | None, list[MicroBatch]]:
+        rows = join_micro_batches(mbs, join_tokens) if token_mode and join_tokens > 0 and passes_are_local else None
+        return rows, ([r.micro_batch for r in rows] if rows is not None else mbs)
+
+    def pieces_of(rows: list[JoinedRows] | None, k: int, came_from: list[int]) -> list[int]:
+        n = len(rows[k].lengths) if rows is not None else 1
+        at = sum(len(r.lengths) for r in rows[:k]) if rows is not None else k
+        return came_from[at : at + n]
+
+    def book(joined: JoinedRows | None, mb: dict[str, Any], loss: Tensor, aux: dict[str, Tensor], came_from: list[int],
+             error: Tensor | None) -> None:
+        nonlocal tokens, passes
+        if joined is not None:
+            losses = restore_row_starts(joined, mb, aux, loss_config, vocab, inv_scale)
+            mask = host_to_device(joined.loss_mask, device)
+        else:
+            losses, mask = loss.detach().reshape(1), mb["loss_mask"]
+        tensors.add("probs", aux["logprobs"], mask, exp=True)
+        tensors.add("old_probs", mb["logprobs"], mask, exp=True)
+        tensors.add("entropy", aux["entropy"], mask)
+        loss_parts.append(losses)
+        loss_rows.extend(came_from)
+        if error is not None:
+            tensors.add("recomputed_logprob_error", error, mask)
+        add_ratio_statistics(tensors, aux, mask, loss_config)
+        tokens += int(mb["input_ids"].numel()) - (joined.padding if joined is not None else 0)
+        passes += 1
+
+    rows_b, units_b = units_of(forward_only)
+    for k, host_mb in enumerate(units_b):
+        mb = to_device(host_mb, device)
+        plan = attention_plan(host_mb, device)
+        with torch.no_grad(), plan_scope(plan):
+            logits = forward(model, mb["input_ids"], mb["position_ids"], plan)
+            vocab = int(logits.shape[-1])
+            loss, aux = policy_loss(logits, mb["input_ids"], mb["position_ids"], mb["advantages"], mb["logprobs"],
+                                    mb["loss_mask"], mb["temperature"], loss_config, loss_scale, skip_masked=True,
+                                    max_sample_len=None if plan is None else plan.lmax)
+            del logits
+        book(rows_b[k] if rows_b is not None else None, mb, loss, aux, pieces_of(rows_b, k, forward_row), None)
+
+    rows, units = units_of(micro_batches)
     if rows is not None and recomputed_errors is not None:
         recomputed_errors = join_per_row(recomputed_errors, rows)
     for step_idx, host_mb in enumerate(units):
@@ -533,21 +694,14 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, micro_batches
                                     positions=keep, max_sample_len=None if plan is None else plan.lmax)
             del logits
             loss.backward(unit_gradient(loss.device))
-        if rows is not None:
-            losses = restore_row_starts(rows[step_idx], mb, aux, loss_config, vocab, 1.0 / max(float(loss_scale), 1.0))
-            mask = host_to_device(rows[step_idx].loss_mask, device)
-        else:
-            losses, mask = loss.detach().reshape(1), mb["loss_mask"]
-        tensors.add("probs", aux["logprobs"], mask, exp=True)
-        tensors.add("old_probs", mb["logprobs"], mask, exp=True)
-        tensors.add("entropy", aux["entropy"], mask)
-        tensors.add("loss", losses)
-        if recomputed_errors is not None:
-            tensors.add("recomputed_logprob_error", recomputed_errors[step_idx], mask)
-        add_ratio_statistics(tensors, aux, mask, loss_config)
-        tokens += int(mb["input_ids"].numel()) - (rows[step_idx].padding if rows is not None else 0)
-    if left_out:
-        tensors.add("loss", torch.zeros(left_out, dtype=torch.float32, device=device))
+        book(rows[step_idx] if rows is not None else None, mb, loss, aux, pieces_of(rows, step_idx, given_row),
+             recomputed_errors[step_idx] if recomputed_errors is not None else None)
+    # one loss per given micro-batch, as the reference logs it; 0 for those not run (nothing scored)
+    tensors.add("loss", losses_per_given_row(loss_parts, loss_rows, n_given, device))
+    if not units:  # nothing to learn from: the optimizer still takes its step, on gradients of zero
+        for prm in model.parameters():
+            if prm.requires_grad and prm.grad is None:
+                prm.grad = torch.zeros_like(prm)
     grad_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=max_norm)
     if hasattr(grad_norm, "full_tensor"):
         grad_norm = grad_norm.full_tensor()
@@ -564,7 +718,7 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, micro_batches
         # synthetic loader that is the micro-batch size
         samples = n_given
     return StepResult(loss=stats.get("loss/mean", float("nan")), grad_norm=float(grad_norm), stats=stats,
-                      seconds=seconds, tokens=tokens, samples=samples, passes=len(units))
+                      seconds=seconds, tokens=tokens, samples=samples, passes=passes)
 
 
 @torch.no_grad()

@@ -486,3 +486,71 @@ def test_lm_head_only_where_the_next_token_is_scored(monkeypatch):
         for k in r0.stats:
             assert r1.stats[k] == pytest.approx(r0.stats[k], rel=5e-3 * (i + 1), abs=1e-6), k
         assert (m1 - m0).norm().item() <= 0.3 * 1e-3 * m0.numel() ** 0.5 * (i + 1)
+
+
+def _rollout_rows(gen, n_rows, vocab, zero_groups):
+    """Rows of four samples of 32 tokens, prompts of 8 tokens masked; the samples named in `zero_groups`
+    (row, sample) have advantage 0 throughout, as every rollout of a group with equal rewards has."""
+    out = rows(gen, n_rows, [32, 32, 32, 32], vocab)
+    for r, mb in enumerate(out):
+        mb["loss_mask"] = mb["loss_mask"] & (mb["position_ids"] >= 8)
+        adv = torch.randn(4, generator=gen).repeat_interleave(32)
+        for (rr, s) in zero_groups:
+            if rr == r:
+                adv[32 * s : 32 * (s + 1)] = 0.0
+        mb["advantages"] = adv.unsqueeze(0)
+    return out
+
+
+@pytest.mark.parametrize("compute_dtype", [torch.float32, torch.bfloat16])
+def test_samples_without_a_gradient_take_a_forward_pass_only(monkeypatch, compute_dtype):
+    """Samples whose advantage is 0 (their group's rollouts all earned the same reward) add exact zeros to the loss
+    and to every gradient: they are run forward only (`trainer.split_by_gradient`), and the step is the one that
+    runs everything forward and backward: statistics (the per-row losses among them), gradient norm, weights."""
+    from prime_rl_cse_amd.optim import FlatAdamW
+
+    gen = torch.Generator().manual_seed(51)
+    zero = [(0, 1), (0, 2), (1, 0), (1, 1), (1, 2), (1, 3), (3, 3)]  # row 1 entirely, row 2 not at all
+    batches = [_rollout_rows(gen, 4, 4096, zero) for _ in range(2)]
+    loss_cfg = prl.LossConfig()
+    results = []
+    for split in ("0", "1"):  # ("1": also for steps as short as these)
+        monkeypatch.setenv("PRL_SPLIT_NO_GRADIENT", split)
+        model = T.get_model(tiny_config(vocab=4096), DEV, torch.float32, seed=11)
+        rep = Replica(model, lambda m: FlatAdamW(m.parameters(), lr=1e-3, weight_decay=0.01),
+                      compute_dtype=compute_dtype)
+        out = []
+        for mbs in batches:
+            res = rep.train_step(copy.deepcopy(mbs), loss_cfg, max_norm=1.0)
+            out.append((res, rep.state.master.detach().clone()))
+        results.append(out)
+    tight = compute_dtype == torch.float32
+    for i, ((r0, m0), (r1, m1)) in enumerate(zip(*results)):
+        # whole: 4 rows of 128 tokens joined into one pass; split: 9 samples to train on, 7 forward only
+        assert (r0.passes, r0.tokens) == (1, 512) and (r1.passes, r1.tokens) == (2, 512) and r1.samples == r0.samples == 4
+        rel = (2e-5 if tight else 5e-3) * (i + 1)
+        assert r1.grad_norm == pytest.approx(r0.grad_norm, rel=rel)
+        assert r1.stats.keys() == r0.stats.keys()
+        for k in r0.stats:
+            assert r1.stats[k] == pytest.approx(r0.stats[k], rel=rel, abs=1e-6), k
+        if tight:
+            torch.testing.assert_close(m1, m0, rtol=1e-4, atol=2e-6)
+        else:
+            assert (m1 - m0).norm().item() <= 0.3 * 1e-3 * m0.numel() ** 0.5 * (i + 1)
+
+
+def test_a_step_with_nothing_to_learn_from_leaves_the_weights_to_weight_decay(monkeypatch):
+    """Every sample with advantage 0: forward passes only, gradient norm 0, and the statistics are still those of
+    the scored tokens."""
+    from prime_rl_cse_amd.optim import FlatAdamW
+
+    monkeypatch.setenv("PRL_SPLIT_NO_GRADIENT", "1")
+    gen = torch.Generator().manual_seed(52)
+    mbs = _rollout_rows(gen, 2, 4096, [(r, s) for r in range(2) for s in range(4)])
+    model = T.get_model(tiny_config(vocab=4096), DEV, torch.float32, seed=11)
+    rep = Replica(model, lambda m: FlatAdamW(m.parameters(), lr=1e-3, weight_decay=0.0), compute_dtype=torch.float32)
+    before = rep.state.master.detach().clone()
+    res = rep.train_step(copy.deepcopy(mbs), prl.LossConfig(), max_norm=1.0)
+    assert res.passes == 1 and res.grad_norm == 0.0 and res.stats["loss/mean"] == 0.0
+    assert res.stats["entropy/mean"] > 0.0 and res.stats["probs/mean"] > 0.0
+    torch.testing.assert_close(rep.state.master.detach(), before, rtol=0, atol=0)

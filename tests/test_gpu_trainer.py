@@ -440,3 +440,37 @@ def test_gathered_lm_head_rows_in_the_plain_trainer_step(monkeypatch):
         assert r1.stats[k] == pytest.approx(r0.stats[k], rel=5e-3, abs=1e-5), k
     for n in g0:
         assert (g1[n] - g0[n]).norm().item() <= 3e-2 * g0[n].norm().item() + 1e-9, n
+
+
+def test_zero_advantage_samples_run_forward_only_in_the_plain_trainer_step(monkeypatch):
+    """`trainer.train_step`: samples with advantage 0 are taken out of the backward pass; gradients, gradient norm
+    and statistics are those of the step that runs every row forward and backward."""
+    cfg = tiny_config()
+    gen = torch.Generator().manual_seed(9)
+    mbs = rows(gen, 3, [32, 32, 32, 32], cfg.vocab_size)
+    for r, mb in enumerate(mbs):
+        mb["loss_mask"] = mb["loss_mask"] & (mb["position_ids"] >= 8)
+        adv = torch.randn(4, generator=gen).repeat_interleave(32)
+        for s in ((1, 3), (0, 1, 2, 3), ())[r]:
+            adv[32 * s : 32 * (s + 1)] = 0.0
+        mb["advantages"] = adv.unsqueeze(0)
+    out = []
+    for split in ("0", "1"):  # ("1": also for steps as short as these)
+        monkeypatch.setenv("PRL_SPLIT_NO_GRADIENT", split)
+        model = T.get_model(cfg, DEV, torch.float32, seed=4)
+        captured = {}
+        hooks = [p.register_post_accumulate_grad_hook(lambda q, n=n: captured.__setitem__(n, q.grad.clone()))
+                 for n, p in model.named_parameters()]
+        res = T.train_step(model, torch.optim.SGD(model.parameters(), lr=0.0), copy.deepcopy(mbs), prl.LossConfig(),
+                           max_norm=1e9, device=DEV)
+        for h in hooks:
+            h.remove()
+        out.append((res, captured))
+    (r0, g0), (r1, g1) = out
+    assert (r0.passes, r1.passes) == (1, 2) and r0.tokens == r1.tokens == 384 and r0.samples == r1.samples == 3
+    assert r1.grad_norm == pytest.approx(r0.grad_norm, rel=2e-5)
+    assert r1.stats.keys() == r0.stats.keys()
+    for k in r0.stats:
+        assert r1.stats[k] == pytest.approx(r0.stats[k], rel=2e-5, abs=1e-6), k
+    for n in g0:
+        torch.testing.assert_close(g1[n], g0[n], rtol=1e-4, atol=1e-6 * float(g0[n].abs().max()) + 1e-12)

@@ -206,3 +206,47 @@ def test_scored_rows_engage_only_where_they_apply(monkeypatch):
     assert T.scored_rows({"loss_mask": torch.zeros(1, t, dtype=torch.bool)}, tok, model(torch.bfloat16, 151936), "cpu") is None
     monkeypatch.setenv("PRL_GATHER_SCORED", "0")
     assert T.scored_rows(mb, tok, model(torch.bfloat16, 151936), "cpu") is None
+
+
+def test_split_by_gradient_sorts_samples_by_whether_anything_can_be_learned_from_them(monkeypatch):
+    from prime_rl_cse_amd import trainer as T
+
+    monkeypatch.setenv("PRL_SPLIT_NO_GRADIENT", "1")  # (the default only separates steps of 16 K tokens and more)
+
+    def row(lens, adv_per_sample, prompt=4, first_scored=False):
+        t = sum(lens)
+        pos = torch.cat([torch.arange(n) for n in lens]).unsqueeze(0)
+        adv = torch.cat([torch.full((n,), float(a)) for n, a in zip(lens, adv_per_sample)]).unsqueeze(0)
+        mask = pos >= prompt
+        if first_scored:
+            mask[0, lens[0]] = True  # the second sample's first token is scored: it depends on its neighbour
+        return {"input_ids": torch.arange(t).unsqueeze(0), "position_ids": pos, "advantages": adv,
+                "logprobs": torch.zeros(1, t), "loss_mask": mask, "temperature": 1.0}
+
+    mixed, dead, alive = row([8, 8, 8], [0.5, 0.0, -0.5]), row([10, 6], [0.0, 0.0]), row([16], [1.0])
+    stuck = row([8, 8], [0.0, 1.0], first_scored=True)
+    unscored_sample = row([8, 3, 8], [1.0, 0.0, 0.0])  # the middle sample is all prompt: dropped
+    grad, grad_row, fwd, fwd_row = T.split_by_gradient([mixed, dead, alive, stuck, unscored_sample])
+    assert grad_row == [0, 0, 2, 3, 4] and fwd_row == [0, 1, 4]
+    assert [m["input_ids"][0].tolist() for m in grad[:2]] == [list(range(0, 8)), list(range(16, 24))]
+    assert fwd[0]["input_ids"][0].tolist() == list(range(8, 16)) and fwd[0]["position_ids"][0].tolist() == list(range(8))
+    assert fwd[1] is dead and grad[2] is alive and grad[3] is stuck  # rows of one kind, or not movable: left whole
+    assert grad[4]["input_ids"][0].tolist() == list(range(0, 8)) and fwd[2]["input_ids"][0].tolist() == list(range(11, 19))
+    assert all(m["temperature"] == 1.0 for m in grad + fwd)
+    assert T.split_by_gradient([alive, row([8, 8], [1.0, 2.0])]) is None  # nothing to separate
+    nan_adv = row([8, 8], [float("nan"), 0.0])
+    g, _, f, _ = T.split_by_gradient([nan_adv])
+    assert len(g) == 1 and len(f) == 1  # a NaN advantage is not "nothing to learn": it has to reach the loss
+    # per-row losses from per-piece losses
+    out = T.losses_per_given_row([torch.tensor([1.0, 2.0, 3.0]), torch.tensor([4.0])], [0, 2, 0, 3], 5, "cpu")
+    assert out.tolist() == [4.0, 0.0, 2.0, 4.0, 0.0]
+    assert T.losses_per_given_row([], [], 3, "cpu").tolist() == [0.0, 0.0, 0.0]
+    # by default short steps stay as they are, long ones are separated
+    monkeypatch.delenv("PRL_SPLIT_NO_GRADIENT")
+    assert T.split_by_gradient([mixed, dead, alive]) is None
+    long_dead, long_alive = row([8192], [0.0]), row([8192], [1.0])
+    g, gr, f, fr = T.split_by_gradient([long_dead, long_alive])
+    assert gr == [1] and fr == [0] and g[0] is long_alive and f[0] is long_dead
+    assert T.split_by_gradient([row([2048], [0.0]), row([16384], [1.0])]) is None  # too little to take out
+    monkeypatch.setenv("PRL_SPLIT_NO_GRADIENT", "0")
+    assert T.split_by_gradient([long_dead, long_alive]) is None

@@ -3,7 +3,7 @@ random prompt / completion lengths, prompt tokens masked, group advantages, firs
 (`prepare_batch`), `rollouts/step_N/rank_0.pt` files, then `train()` reading them.
 
 usage: python tools/ragged_rollouts_run.py [--model NAME] [--seq-len 128] [--micro-batch 16] [--batch 128]
-                                            [--steps 4] [--max-completion N]"""
+                                            [--steps 4] [--max-completion N] [--settled SHARE]"""
 import argparse, os, sys, tempfile
 from pathlib import Path
 
@@ -29,12 +29,20 @@ p.add_argument("--group", type=int, default=16)
 p.add_argument("--steps", type=int, default=4)
 p.add_argument("--max-completion", type=int, default=None)
 p.add_argument("--temperature", type=float, default=1.0)
+p.add_argument("--settled", type=float, default=None,
+               help="rewards are 0 or 1, and this share of the problems is always solved or never solved (every "
+                    "rollout of such a group has the same reward, so its group-relative advantage is 0)")
 args = p.parse_args()
 
 rng = np.random.default_rng(0)
 out = Path(tempfile.mkdtemp())
 for step in range(args.steps):
-    rewards = rng.random(args.batch).round(1).tolist()
+    if args.settled is None:
+        rewards = rng.random(args.batch).round(1).tolist()
+    else:
+        n_prob = args.batch // args.group
+        p_solve = np.where(rng.random(n_prob) < args.settled, rng.integers(0, 2, n_prob).astype(float), 0.5)
+        rewards = (rng.random(args.batch) < np.repeat(p_solve, args.group)).astype(float).tolist()
     rollouts, lengths = [], []
     for i in range(args.batch):
         n_prompt = int(rng.integers(10, max(11, args.seq_len // 3)))
