@@ -798,6 +798,15 @@ class Replica:
         tensors.add("loss", losses_per_given_row(loss_parts, loss_rows, n_given, self.device))
         if not units:  # nothing to learn from on this rank: its share of the mean is zero, not last step's sums
             self.state.acc32.zero_()
+            if self.overlap:
+                # the other ranks start their reduce-scatters from inside a backward pass: every bucket but the
+                # embedding table's back to front, then that one; collectives have to come in one order everywhere
+                for b in reversed(self.state.buckets):
+                    if not b.held:
+                        self.state.reduce_bucket(b)
+                for b in self.state.buckets:
+                    if b.held:
+                        self.state.reduce_bucket(b)
             grad_norm = self.state.finish_step(self.optimizer, max_norm, keep_sums=not self.graphs,
                                                gathers_in_flight=self.overlap)
         if scheduler is not None:

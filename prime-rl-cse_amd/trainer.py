@@ -622,6 +622,10 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, micro_batches
         split = split_by_gradient(micro_batches)
         if split is not None:
             micro_batches, rows_a, forward_only, rows_b = split
+            if not micro_batches and not one_rank and hasattr(model, "unshard"):
+                # FSDP2 issues the step's reduce-scatters from inside a backward pass: a rank whose samples all
+                # have advantage 0 still runs one (over gradients of zero), or the other ranks would wait for it
+                micro_batches, rows_a, forward_only, rows_b = forward_only[:1], rows_b[:1], forward_only[1:], rows_b[1:]
             forward_row = [given_row[i] for i in rows_b]
             given_row = [given_row[i] for i in rows_a]
     inv_scale = 1.0 / max(float(loss_scale), 1.0)

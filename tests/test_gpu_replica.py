@@ -326,7 +326,7 @@ def _param_steps(before, model):
     return torch.cat([(b - p.detach()).reshape(-1) for b, p in zip(before, model.parameters())])
 
 
-def _replica_rank(rank, world, port, q, seed, bucket_bytes):
+def _replica_rank(rank, world, port, q, seed, bucket_bytes, idle_rank=None):
     """One of two ranks that share the GPU and exchange over gloo (through host memory): a step of `Replica` on
     this rank's own micro-batches."""
     import os
@@ -342,6 +342,11 @@ def _replica_rank(rank, world, port, q, seed, bucket_bytes):
     try:
         gen = torch.Generator().manual_seed(seed + rank)
         mbs = rows(gen, 2 + rank, [24, 8, 32], 4096)  # the ranks hold different numbers of rows and of tokens
+        if idle_rank is not None:
+            os.environ["PRL_SPLIT_NO_GRADIENT"] = "1"
+            if rank == idle_rank:  # every group settled: nothing to learn from on this rank, forward passes only
+                for mb in mbs:
+                    mb["advantages"] = torch.zeros_like(mb["advantages"])
         model = T.get_model(tiny_config(vocab=4096), DEV, torch.float32, seed=11)
         rep = Replica(model, lambda m: torch.optim.SGD(m.parameters(), lr=1.0), compute_dtype=torch.float32,
                       bucket_bytes=bucket_bytes)
@@ -402,6 +407,37 @@ def test_two_ranks_take_the_mean_of_their_own_steps(bucket_bytes):
         else:
             assert n_buckets == 1 and launched == 0
     assert torch.equal(results[0][1], results[1][1]) and results[0][4] == results[1][4]
+
+
+def test_a_rank_with_nothing_to_learn_from_still_takes_part_in_the_exchange():
+    """Two ranks (gloo, sharing the GPU), buckets reduced from inside backward: one rank's samples all have
+    advantage 0, so it runs forward passes only and has no backward pass to start its reduce-scatters from; it
+    issues them in the order the other rank's backward does, and both end with half of the other rank's step."""
+    import torch.multiprocessing as mp
+
+    seed, bucket_bytes = 78, 4 * 40000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_replica_rank, args=(r, 2, 29747, q, seed, bucket_bytes, 1)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0, results
+    results = sorted(((r, torch.from_numpy(step), *rest) for r, step, *rest in results), key=lambda x: x[0])
+    gen = torch.Generator().manual_seed(seed)
+    mbs = rows(gen, 2, [24, 8, 32], 4096)
+    model = T.get_model(tiny_config(vocab=4096), DEV, torch.float32, seed=11)
+    rep = Replica(model, lambda m: torch.optim.SGD(m.parameters(), lr=1.0), compute_dtype=torch.float32)
+    before = [p.detach().clone() for p in model.parameters()]
+    rep.train_step(mbs, prl.LossConfig(), max_norm=1e9, join_tokens=0)
+    want = 0.5 * _param_steps(before, model).cpu()
+    for rank, step, norm, loss, entropy, n_buckets, launched in results:
+        torch.testing.assert_close(step, want, rtol=1e-4, atol=1e-5 * want.abs().max().item())
+        assert norm == pytest.approx(want.norm().item(), rel=1e-4)
+        assert n_buckets == 3 and launched == (2 if rank == 0 else 0)
+    assert torch.equal(results[0][1], results[1][1])
 
 
 def test_exchange_inside_backward_over_rccl_leaves_the_single_rank_step_unchanged(monkeypatch):
