@@ -385,8 +385,15 @@ def split_by_gradient(micro_batches: list[MicroBatch]
         return {k: (v[:, a:z] if isinstance(v, Tensor) and v.ndim == 2 else v) for k, v in mb.items()}
 
     for r, mb in enumerate(micro_batches):
+        # (the common case, settled first and through numpy: this runs with the GPU waiting for the step)
+        adv = mb["advantages"]
+        if adv.dtype == torch.float32 and np.count_nonzero(adv.numpy()) == adv.numel():
+            grad.append(mb)
+            grad_row.append(r)
+            continue
+        zero = adv[0] == 0
         mask = mb["loss_mask"][0].to(torch.bool)
-        live = mask & (mb["advantages"][0] != 0)  # (a NaN advantage counts: its NaN must reach the loss)
+        live = mask & ~zero  # (a NaN advantage counts: its NaN must reach the loss)
         if not bool(mask.any()) or bool(live[mask].all()):  # nobody scored (the caller's business), or all live
             grad.append(mb)
             grad_row.append(r)
