@@ -334,8 +334,13 @@ def scored_rows(host_micro_batch: MicroBatch, loss_config: LossConfig, model: nn
     if dtype != torch.bfloat16 or vocab < 8 or \
             not C.load().prl_policy_rows_supported(C.PRL_BF16, 1, vocab, vocab, C.PRL_BF16, vocab):
         return None
+    import numpy as np
+
+    n_scored = int(np.count_nonzero(mask.numpy()[0, 1:]))  # (cheap, and settles the rows where every token is scored)
+    if n_scored == 0 or n_scored > GATHER_AT_MOST * (mask.shape[1] - 1):
+        return None
     keep = scored_positions(mask, multiple=GATHER_MULTIPLE)
-    if keep.numel() == 0 or keep.numel() > GATHER_AT_MOST * (mask.shape[1] - 1):
+    if keep.numel() > GATHER_AT_MOST * (mask.shape[1] - 1):
         return None
     return host_to_device(keep, device, torch.int64)
 
