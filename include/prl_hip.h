@@ -260,6 +260,10 @@ int prl_policy_rows_time_next(void* start_event, void* stop_event);
  * Every token that no row predicts comes back unscored (logprob = entropy = lse = 0), as skip_masked = 1 leaves a
  * masked token; token 0 is scored against an all-zero row when mask[0] is set; a listed row whose token is masked
  * out is not read (zero gradient row, token unscored).  R = 0 is allowed.  Follow with prl_policy_tail as usual.
+ *
+ * dlogits = NULL: the rows are only scored (logprob, entropy, lse as above), nothing is differentiated and
+ * out_dtype / out_row_stride are ignored.  For passes that need the logged values but no gradient: the reference's
+ * logprob recompute (src/prime_rl/trainer/rl/train.py:227-245) and rows whose advantages are all zero.
  */
 int prl_policy_rows_gathered_fwd_bwd(const void* logits, int logits_dtype, int64_t R, int64_t V, int64_t row_stride,
                                      const int64_t* positions, int64_t T, const int64_t* ids, const float* adv,

@@ -118,7 +118,8 @@ __device__ __forceinline__ void store_chunk(const u32x4& v, R rsrc, uint32_t vof
 // first chunk then waits for this row's stores; workgroups that simply walk over several rows, one
 // or two per compute unit, were no faster than fresh workgroups and cost registers; pulling a later
 // row towards the caches with one dword per line cost 25 %.)
-template <int NCH>
+// GRAD = false: the row is only scored (logprob, entropy, lse); `dlogits` is not touched and may be NULL.
+template <int NCH, bool GRAD = true>
 __global__ __launch_bounds__(kRowThreads) void k_policy_rows(
     const char* __restrict__ logits, int64_t T, int64_t V, int64_t in_stride_bytes, const int64_t* __restrict__ ids,
     const float* __restrict__ old, const float* __restrict__ adv, const uint32_t* __restrict__ mask_words,
@@ -157,9 +158,11 @@ __global__ __launch_bounds__(kRowThreads) void k_policy_rows(
   const auto out_rsrc =
       __builtin_amdgcn_make_buffer_rsrc(dlogits + row * out_stride_bytes, 0, row_bytes, kRsrcFlags);
   auto zero_row = [&]() {
-    const u32x4 z = {0u, 0u, 0u, 0u};
+    if constexpr (GRAD) {
+      const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) store_chunk(z, out_rsrc, lane_off, j * kSlab);
+      for (int j = 0; j < NCH; ++j) store_chunk(z, out_rsrc, lane_off, j * kSlab);
+    }
   };
 
   if (positions && (at < 0 || at >= T - 1)) {  // a position outside the packed row: nothing is read, nothing is emitted
@@ -304,6 +307,7 @@ __global__ __launch_bounds__(kRowThreads) void k_policy_rows(
     if (lp_out) lp_out[t] = lp;
     if (ent_out) ent_out[t] = lse - (w / s) * inv_temp;
   }
+  if constexpr (!GRAD) return;
   const float r = expf(lp - old_t);
   const float through = (r <= clip) ? -(inv_scale * adv_t) : 0.0f;
   const float g = m ? through * r : 0.0f;
@@ -1276,11 +1280,15 @@ extern "C" int prl_policy_rows_gathered_fwd_bwd(const void* logits, int logits_d
                      mask, T, V);
   PRL_CHECK_LAUNCH("policy_rows_gathered_fwd_bwd (unscored tokens)");
   if (R == 0) return PRL_OK;
+  if (!dlogits) {  // rows are only scored: the gradient's type and stride play no part
+    out_dtype = PRL_BF16;
+    out_row_stride = row_stride;
+  }
   PRL_REQUIRE(prl_policy_rows_supported(logits_dtype, R, V, row_stride, out_dtype, out_row_stride),
               "policy_rows_gathered_fwd_bwd: shape or dtype not supported (needs bf16 in and out, V a multiple of 8 "
               "and at most %d, row strides multiples of 8)",
               kRowMaxChunks * kRowThreads * 8);
-  PRL_REQUIRE(logits && dlogits && positions, "policy_rows_gathered_fwd_bwd: logits, dlogits and positions must not be NULL");
+  PRL_REQUIRE(logits && positions, "policy_rows_gathered_fwd_bwd: logits and positions must not be NULL");
   PRL_REQUIRE(((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits)) & 15) == 0,
               "policy_rows_gathered_fwd_bwd: logits and dlogits must be 16-byte aligned");
   const float scale = loss_scale > 1.0f ? loss_scale : 1.0f;  // max(loss_scale, 1)
@@ -1294,10 +1302,17 @@ extern "C" int prl_policy_rows_gathered_fwd_bwd(const void* logits, int logits_d
   const int mask_mis = (int)(reinterpret_cast<uintptr_t>(mask) & 3);
   const uint32_t* mask_words = reinterpret_cast<const uint32_t*>(mask - mask_mis);
   // skip_masked = 1: a listed row whose token is masked out is not read; it gets a zero gradient row
-#define PRL_ROWS(N)                                                                                                \
-  hipLaunchKernelGGL((k_policy_rows<N>), grid, block, 0, st, (const char*)logits, T, V, row_stride * 2, ids, old, \
-                     adv, mask_words, mask_mis, 1, inv_temp, clip_ratio, 1.0f / scale, logprob, entropy, lse,      \
-                     (char*)dlogits, out_row_stride * 2, positions, R)
+#define PRL_ROWS_GATHERED_ARGS                                                                                  \
+  (const char*)logits, T, V, (int64_t)(row_stride * 2), ids, old, adv, mask_words, mask_mis, 1, inv_temp,      \
+      clip_ratio, (float)(1.0f / scale), logprob, entropy, lse, (char*)dlogits, (int64_t)(out_row_stride * 2), \
+      positions, R
+#define PRL_ROWS(N)                                                                                           \
+  do {                                                                                                        \
+    if (dlogits)                                                                                              \
+      hipLaunchKernelGGL((k_policy_rows<N, true>), grid, block, 0, st, PRL_ROWS_GATHERED_ARGS);               \
+    else                                                                                                      \
+      hipLaunchKernelGGL((k_policy_rows<N, false>), grid, block, 0, st, PRL_ROWS_GATHERED_ARGS);              \
+  } while (0)
   if (need <= 2)
     PRL_ROWS(2);
   else if (need <= 4)
@@ -1311,6 +1326,7 @@ extern "C" int prl_policy_rows_gathered_fwd_bwd(const void* logits, int logits_d
   else
     PRL_ROWS(19);
 #undef PRL_ROWS
+#undef PRL_ROWS_GATHERED_ARGS
   PRL_CHECK_LAUNCH("policy_rows_gathered_fwd_bwd");
   return PRL_OK;
 #endif

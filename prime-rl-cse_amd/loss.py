@@ -398,14 +398,16 @@ class _PolicyLoss(torch.autograd.Function):
         fp, ip = f.data_ptr(), iarena.data_ptr()
         at = lambda k: C.c_void_p(fp + 4 * t * k)
         code, st = C.dtype_code(logits), C.stream_ptr(dev)
-        single_pass = (
-            not per_seq and t > 0 and ctx.needs_input_grad[0] and _rows_kernel_enabled()
-            and logits.data_ptr() % 16 == 0
+        rows_kernel = (
+            not per_seq and t > 0 and _rows_kernel_enabled() and logits.data_ptr() % 16 == 0
             and bool(lib.prl_policy_rows_supported(code, max(n_rows, 1), v, logits.stride(1) if n_rows else v, code, v))
         )
-        if positions is not None and not single_pass:
-            raise ValueError("policy_loss: gathered rows (`positions`) need ratio_type 'token', bf16 logits that "
-                             "require a gradient, a vocabulary that is a multiple of 8 and at most 155648, and T > 0")
+        single_pass = rows_kernel and ctx.needs_input_grad[0]
+        # gathered rows nobody wants a gradient of: the same kernel, scoring only
+        gathered_forward = rows_kernel and positions is not None and not ctx.needs_input_grad[0]
+        if positions is not None and not (single_pass or gathered_forward):
+            raise ValueError("policy_loss: gathered rows (`positions`) need ratio_type 'token', bf16 logits, a "
+                             "vocabulary that is a multiple of 8 and at most 155648, and T > 0")
         seq_limits = _seq_rows_limits() if per_seq else None
         if seq_limits is not None and max_sample_len is not None and int(max_sample_len) > seq_limits[0]:
             # a sample too long for its workgroups to wait for each other: its rows would all be left to the second
@@ -455,10 +457,10 @@ class _PolicyLoss(torch.autograd.Function):
                     )
             ctx.dlogits = dlogits
             _LAST_SEQ_PENDING[0] = pending
-        elif single_pass and positions is not None:
+        elif positions is not None:
             # the LM head ran only where the next token is scored: row r of the logits belongs to position
             # positions[r]; every per-token result still comes back in the packed row's layout
-            dlogits = torch.empty((1, n_rows, v), dtype=logits.dtype, device=dev)
+            dlogits = torch.empty((1, n_rows, v), dtype=logits.dtype, device=dev) if single_pass else None
             with C.on_device(dev):
                 with C.timed("prl_policy_rows_gathered_fwd_bwd", dev):
                     C.check(
@@ -466,7 +468,7 @@ class _PolicyLoss(torch.autograd.Function):
                             C.ptr(logits) if n_rows else None, code, n_rows, v, logits.stride(1) if n_rows else v,
                             C.ptr(positions) if n_rows else None, t, C.ptr(ids), C.ptr(adv), C.ptr(old), C.ptr(mask),
                             temperature, clip, float(loss_scale), at(0), at(1), at(2),
-                            C.ptr(dlogits) if n_rows else None, code, v, st,
+                            C.ptr(dlogits) if n_rows and single_pass else None, code, v, st,
                         ),
                         "prl_policy_rows_gathered_fwd_bwd",
                     )
@@ -521,7 +523,9 @@ class _PolicyLoss(torch.autograd.Function):
         ratio, clipped, is_clipped = parts[4][:n_aux], parts[5][:n_aux], parts[6][:n_aux]
         seg_start = iarena[: t + 1]
         n_seg = iarena[t + 1 :].view(torch.int32)[:1]
-        single_pass = single_pass or seq_pass  # either way the gradient exists already and backward hands it out
+        # either way the gradient exists already and backward hands it out (or, for rows that were only scored,
+        # nothing asks for one)
+        single_pass = single_pass or seq_pass or gathered_forward
         ctx.single_pass = single_pass
         if not single_pass:
             ctx.save_for_backward(logits, ids.view(1, t), lse, g)
@@ -603,7 +607,7 @@ def policy_loss(
     these positions of the packed row (`scored_positions` picks the ones whose next token is scored), row r
     predicting token positions[r] + 1.  Everything per token still has T entries; tokens that no row predicts
     come back unscored, as `skip_masked=True` leaves masked tokens, and the gradient is [1, R, V].  Token mode
-    with bf16 logits only.  With prompts masked out this takes their share out of the LM head's three products
+    with bf16 logits only; logits that need no gradient (a pass under `torch.no_grad()`) are only scored.  With prompts masked out this takes their share out of the LM head's three products
     and out of the pass over the logits; loss, gradient and masked statistics are unchanged."""
     if logits.ndim != 3 or logits.shape[0] != 1:
         raise ValueError(f"policy_loss takes one packed row, logits [1, T, V]; got {tuple(logits.shape)}")

@@ -766,11 +766,12 @@ class Replica:
         for k, host_mb in enumerate(units_b):
             mb = to_device(host_mb, self.device)
             plan = attention_plan(host_mb, self.device)
+            keep = scored_rows(host_mb, loss_config, self.model, self.device)
             with torch.no_grad():
-                logits = forward(self.model, mb["input_ids"], mb["position_ids"], plan)
+                logits = forward(self.model, mb["input_ids"], mb["position_ids"], plan, positions=keep)
                 loss, aux = policy_loss(logits, mb["input_ids"], mb["position_ids"], mb["advantages"], mb["logprobs"],
                                         mb["loss_mask"], mb["temperature"], loss_config, 1.0, skip_masked=True,
-                                        max_sample_len=None if plan is None else plan.lmax)
+                                        positions=keep, max_sample_len=None if plan is None else plan.lmax)
                 del logits
             book(rows_b[k] if rows_b is not None else None, mb, loss, aux, pieces_of(rows_b, k, forward_row)[0], None)
 

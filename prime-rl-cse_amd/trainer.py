@@ -678,12 +678,13 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, micro_batches
     for k, host_mb in enumerate(units_b):
         mb = to_device(host_mb, device)
         plan = attention_plan(host_mb, device)
+        keep = scored_rows(host_mb, loss_config, model, device)
         with torch.no_grad(), plan_scope(plan):
-            logits = forward(model, mb["input_ids"], mb["position_ids"], plan)
+            logits = forward(model, mb["input_ids"], mb["position_ids"], plan, positions=keep)
             vocab = int(logits.shape[-1])
             loss, aux = policy_loss(logits, mb["input_ids"], mb["position_ids"], mb["advantages"], mb["logprobs"],
                                     mb["loss_mask"], mb["temperature"], loss_config, loss_scale, skip_masked=True,
-                                    max_sample_len=None if plan is None else plan.lmax)
+                                    positions=keep, max_sample_len=None if plan is None else plan.lmax)
             del logits
         book(rows_b[k] if rows_b is not None else None, mb, loss, aux, pieces_of(rows_b, k, forward_row), None)
 

@@ -131,3 +131,56 @@ def test_gathered_rows_refuse_what_the_kernel_cannot_do():
     with pytest.raises(ValueError, match="one position per row"):
         prl.policy_loss(rows.clone().requires_grad_(True), on(ids), on(pos), on(adv), on(old), on(mask), 1.0,
                         prl.LossConfig(), 1, positions=keep[:-1])
+
+
+@pytest.mark.parametrize("vocab,temp,mask_p,multiple", [(1000, 0.7, 0.5, 1), (151936, 1.0, 0.4, 16), (152064, 0.6, 0.7, 1)])
+def test_gathered_rows_that_need_no_gradient_are_only_scored(vocab, temp, mask_p, multiple):
+    """Under `torch.no_grad()` (forward-only passes): the same per-token values, loss and logged tensors as the
+    gathered call that also differentiates, bit for bit, and nothing to call backward on."""
+    dev = torch.device(DEV)
+    logits, ids, pos, mask, adv, old = seeded_case(7 + vocab % 89, [11, 2, 25, 14], 2, vocab, temp, mask_p=mask_p)
+    cfg = prl.LossConfig(clip_ratio=1.15)
+    t = ids.numel()
+    on = lambda x: x.to(dev).view(1, t)
+    args = (on(ids), on(pos), on(adv), on(old), on(mask))
+    keep = prl.scored_positions(mask, multiple=multiple).to(dev)
+    rows = logits.to(dev)[:, keep, :].clone()
+    loss_g, aux_g = prl.policy_loss(rows.clone().requires_grad_(True), *args, temp, cfg, int(mask.sum()), positions=keep)
+    with torch.no_grad():
+        loss_n, aux_n = prl.policy_loss(rows, *args, temp, cfg, int(mask.sum()), positions=keep)
+    # ... and without autograd switched off, for logits that simply need no gradient
+    loss_p, aux_p = prl.policy_loss(rows, *args, temp, cfg, int(mask.sum()), positions=keep)
+    torch.cuda.synchronize()
+    assert not loss_n.requires_grad and not loss_p.requires_grad
+    for loss, aux in ((loss_n, aux_n), (loss_p, aux_p)):
+        assert torch.equal(loss.cpu(), loss_g.detach().cpu())
+        for k in ("logprobs", "entropy", "importance_ratio", "clipped_importance_ratio", "is_clipped", "n_seg"):
+            assert torch.equal(aux[k].cpu(), aux_g[k].cpu()), k
+    assert bool(aux_n["logprobs"].any())
+
+
+def test_score_only_call_through_the_c_abi_leaves_the_gradient_alone():
+    """dlogits = NULL: logprob, entropy and lse as with a gradient buffer, whatever out_dtype / out_row_stride say."""
+    dev = torch.device(DEV)
+    lib = C.load()
+    logits, ids, pos, mask, adv, old = seeded_case(21, [16, 9, 30], 0, 32000, 0.8, mask_p=0.6)
+    t, v = ids.numel(), 32000
+    keep = prl.scored_positions(mask, multiple=8).to(dev)
+    r = keep.numel()
+    rows = logits[0].to(dev)[keep].contiguous()
+    ids_d, adv_d, old_d, mask_d = ids.to(dev), adv.to(dev), old.to(dev), mask.to(torch.uint8).to(dev)
+    out = []
+    for with_gradient in (True, False):
+        lp, ent, lse = (torch.full((t,), 7.0, device=dev) for _ in range(3))
+        d = torch.full((r, v), 7.0, dtype=torch.bfloat16, device=dev)
+        C.check(lib.prl_policy_rows_gathered_fwd_bwd(
+            C.ptr(rows), C.PRL_BF16, r, v, v, C.ptr(keep), t, C.ptr(ids_d), C.ptr(adv_d), C.ptr(old_d), C.ptr(mask_d),
+            0.8, 8.0, float(mask.sum()), C.ptr(lp), C.ptr(ent), C.ptr(lse), C.ptr(d) if with_gradient else None,
+            C.PRL_BF16 if with_gradient else -5, v if with_gradient else 3, C.stream_ptr(dev)),
+            "prl_policy_rows_gathered_fwd_bwd")
+        torch.cuda.synchronize()
+        out.append((lp.cpu(), ent.cpu(), lse.cpu(), d.cpu()))
+    for a, b in zip(out[0][:3], out[1][:3]):
+        assert torch.equal(a, b)
+    assert bool(out[0][0].any()) and not bool((out[0][3] == 7.0).any())
+    assert bool((out[1][3] == 7.0).all())  # the buffer the second call never saw
