@@ -391,31 +391,31 @@ def split_by_gradient(micro_batches: list[MicroBatch]
 
     for r, mb in enumerate(micro_batches):
         # (the common case, settled first and through numpy: this runs with the GPU waiting for the step)
-        adv = mb["advantages"]
-        if adv.dtype == torch.float32 and np.count_nonzero(adv.numpy()) == adv.numel():
+        adv = mb["advantages"][0].numpy()
+        if np.count_nonzero(adv) == adv.size:
             grad.append(mb)
             grad_row.append(r)
             continue
-        zero = adv[0] == 0
-        mask = mb["loss_mask"][0].to(torch.bool)
-        live = mask & ~zero  # (a NaN advantage counts: its NaN must reach the loss)
-        if not bool(mask.any()) or bool(live[mask].all()):  # nobody scored (the caller's business), or all live
+        mask = mb["loss_mask"][0].numpy().astype(bool)
+        live = mask & (adv != 0)  # (a NaN advantage counts: its NaN must reach the loss)
+        n_scored, n_live = int(np.count_nonzero(mask)), int(np.count_nonzero(live))
+        if n_scored == 0 or n_live == n_scored:  # nobody scored (the caller's business), or all live
             grad.append(mb)
             grad_row.append(r)
             continue
-        if not bool(live.any()):  # scored, but nothing to learn from: the whole row forward only
+        if n_live == 0:  # scored, but nothing to learn from: the whole row forward only
             fwd.append(mb)
             fwd_row.append(r)
             changed = True
             continue
         starts = sample_starts(mb["position_ids"])
-        n = int(mask.numel())
-        any_live = np.add.reduceat(live.numpy().astype(np.int64), starts) > 0
-        if bool(any_live.all()) or bool(mask[torch.from_numpy(starts)].any()):
+        n = int(mask.size)
+        any_live = np.add.reduceat(live.astype(np.int64), starts) > 0
+        if bool(any_live.all()) or bool(mask[starts].any()):
             grad.append(mb)  # every sample has live tokens, or a sample cannot be moved
             grad_row.append(r)
             continue
-        any_scored = np.add.reduceat(mask.numpy().astype(np.int64), starts) > 0
+        any_scored = np.add.reduceat(mask.astype(np.int64), starts) > 0
         ends = np.append(starts[1:], n)
         for a, z, lv, sc in zip(starts.tolist(), ends.tolist(), any_live.tolist(), any_scored.tolist()):
             if lv:
@@ -579,8 +579,10 @@ def restore_row_starts(rows: JoinedRows, mb: dict[str, Any], aux: dict[str, Tens
         ln_v = float(torch.log(torch.tensor(float(vocab), dtype=torch.float32)))
         old = mb["logprobs"].reshape(-1)[idx].float()
         ratio = torch.exp(-ln_v - old)
-        aux["logprobs"].reshape(-1)[idx] = -ln_v
-        aux["entropy"].reshape(-1)[idx] = ln_v
+        # (index_fill_ takes the number as a kernel argument; `x[idx] = number` would make a host tensor of it and
+        # copy that to the device out of pageable memory, which waits for everything the stream still holds)
+        aux["logprobs"].reshape(-1).index_fill_(0, idx, -ln_v)
+        aux["entropy"].reshape(-1).index_fill_(0, idx, ln_v)
         aux["importance_ratio"][idx] = ratio
         aux["clipped_importance_ratio"][idx] = torch.clamp(ratio, max=float(loss_config.clip_ratio))
         aux["is_clipped"][idx] = (ratio > float(loss_config.clip_ratio)).float()
