@@ -579,8 +579,8 @@ def restore_row_starts(rows: JoinedRows, mb: dict[str, Any], aux: dict[str, Tens
         ln_v = float(torch.log(torch.tensor(float(vocab), dtype=torch.float32)))
         old = mb["logprobs"].reshape(-1)[idx].float()
         ratio = torch.exp(-ln_v - old)
-        # (index_fill_ takes the number as a kernel argument; `x[idx] = number` would make a host tensor of it and
-        # copy that to the device out of pageable memory, which waits for everything the stream still holds)
+        # (index_fill_ takes the number as a kernel argument.  `x[idx] = number` keeps the host until the stream
+        # has drained, `tools/setitem_sync_probe.py`: once per pass, that was 15 % of a step of ten passes)
         aux["logprobs"].reshape(-1).index_fill_(0, idx, -ln_v)
         aux["entropy"].reshape(-1).index_fill_(0, idx, ln_v)
         aux["importance_ratio"][idx] = ratio
@@ -771,7 +771,8 @@ def recompute_logprobs(logprob_model: nn.Module, micro_batches: list[MicroBatch]
         del logits
         if len(r.starts) > 1:
             idx = host_to_device(r.starts[1:], device, torch.int64)
-            lp[:, idx] = -float(torch.log(torch.tensor(float(logprob_model.config.vocab_size), dtype=torch.float32)))
+            ln_v = float(torch.log(torch.tensor(float(logprob_model.config.vocab_size), dtype=torch.float32)))
+            lp.index_fill_(1, idx, -ln_v)  # (not `lp[:, idx] = number`, which waits for the stream)
         for a, n in zip(r.starts, r.lengths):  # back to the micro-batches the caller holds
             piece = lp[:, a : a + n]
             errors.append(torch.exp(piece - host_to_device(micro_batches[k]["logprobs"], device)))
