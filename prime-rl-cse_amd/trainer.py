@@ -587,11 +587,11 @@ def restore_row_starts(rows: JoinedRows, mb: dict[str, Any], aux: dict[str, Tens
         aux["clipped_importance_ratio"][idx] = torch.clamp(ratio, max=float(loss_config.clip_ratio))
         aux["is_clipped"][idx] = (ratio > float(loss_config.clip_ratio)).float()
     term = -(aux["clipped_importance_ratio"] * mb["advantages"].reshape(-1).float()) * mask * inv_scale
-    per_row, a = [], 0
-    for n in rows.lengths:
-        per_row.append(term[a : a + n].sum())
-        a += n
-    return torch.stack(per_row)
+    # one launch for all rows (a joined row of ragged rollouts has a hundred pieces, and this runs between passes)
+    lengths = list(rows.lengths) + ([term.numel() - sum(rows.lengths)] if term.numel() > sum(rows.lengths) else [])
+    # (`unsafe`: the lengths are not checked, which would read them back and keep the host until the stream drains)
+    sums = torch.segment_reduce(term, "sum", lengths=host_to_device(lengths, dev, torch.int64), unsafe=True)
+    return sums[: len(rows.lengths)]
 
 
 def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, micro_batches: list[MicroBatch],
