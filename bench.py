@@ -246,6 +246,9 @@ def trainer_measure(dev, world: int, steps: int, warmup: int, cpu: bool, cpu_sec
     batches = [loader.get_batch() for _ in range(2)]
     for i in range(warmup):
         step(batches[i % 2])
+    from prime_rl_cse_amd.train import freeze_setup_objects
+
+    freeze_setup_objects()  # as the trainer's entry point does after its first steps
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
