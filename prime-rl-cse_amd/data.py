@@ -71,6 +71,9 @@ class FakeDataLoader:
     def wait_for_batch(self) -> None:
         """Nothing to wait for."""
 
+    def ready(self) -> bool:
+        return True
+
     def get_batch(self) -> list[MicroBatch]:
         c = self.config
         return [synthetic_row(c.micro_batch_size, c.seq_len, self.generator) for _ in range(self.num_micro_batches)]
@@ -90,6 +93,11 @@ class DataLoader:
 
     def wait_for_batch(self, interval: float = 1.0, timeout: float | None = None) -> None:
         wait_for_path(self.get_rollout_path(), interval, timeout)
+
+    def ready(self) -> bool:
+        """Whether the next step's file is there already (the orchestrator renames it into place when it is
+        complete, src/prime_rl/orchestrator/orchestrator.py:356-363): `get_batch` would not have to wait."""
+        return self.get_rollout_path().exists()
 
     def get_batch(self) -> list[MicroBatch]:
         # a list of dicts of tensors and floats: nothing in it needs unpickling of code

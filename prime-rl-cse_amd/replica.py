@@ -693,22 +693,19 @@ class Replica:
 
     # ------------------------------------------------------------------ one optimizer step
 
-    def train_step(self, micro_batches: list[MicroBatch], loss_config: LossConfig, max_norm: float | None = 1.0,
-                   scheduler: Any = None, samples: int | None = None,
-                   recomputed_errors: list[Tensor] | None = None, join_tokens: int | None = None,
-                   skip_unscored: bool = True) -> Any:
-        """One optimizer step over this rank's micro-batches (src/prime_rl/trainer/rl/train.py:259-364);
-        same results and the same `StepResult` as `trainer.train_step`, micro-batches joined the same way and
-        fillers left out the same way (`trainer.scored`)."""
-        from .trainer import (MERGE_MAX_TOKENS, StepResult, attention_plan, join_micro_batches, join_per_row,
-                              add_ratio_statistics, forward, local_loss_scale, losses_per_given_row,
-                              ones_as_recomputed_error, restore_row_starts, scored, scored_rows, split_by_gradient)
+    def prepare_step(self, micro_batches: list[MicroBatch], loss_config: LossConfig,
+                     recomputed_errors: list[Tensor] | None = None, join_tokens: int | None = None,
+                     skip_unscored: bool = True) -> dict[str, Any]:
+        """The host's share of a step before anything runs: fillers left out (`trainer.scored`), samples without a
+        gradient sorted out (`trainer.split_by_gradient`), rows joined (`trainer.join_micro_batches`).  Touches
+        host tensors only (unless `recomputed_errors`, device tensors, are given), so the caller may do it for
+        the NEXT step while this step's kernels still run; hand the result to `train_step(prepared=...)`."""
+        from .trainer import (MERGE_MAX_TOKENS, join_micro_batches, join_per_row, local_loss_scale, scored,
+                              split_by_gradient)
 
         join_tokens = MERGE_MAX_TOKENS if join_tokens is None else join_tokens
-        t0 = time.perf_counter()
         n_given = len(micro_batches)
         inv_scale = 1.0 / max(float(local_loss_scale(micro_batches, loss_config)), 1.0)
-        self._starts_sums = not self.graphs
         token_mode = loss_config.ratio_type == "token"
         given_row = list(range(n_given))  # the given row every micro-batch still in the list came from
         if skip_unscored and token_mode:
@@ -726,16 +723,49 @@ class Replica:
                 micro_batches, rows_a, forward_only, rows_b = split
                 forward_row = [given_row[i] for i in rows_b]
                 given_row = [given_row[i] for i in rows_a]
+
+        def units_of(mbs: list[MicroBatch]) -> tuple[list[Any] | None, list[MicroBatch]]:
+            rows = join_micro_batches(mbs, join_tokens) if token_mode and join_tokens > 0 else None
+            return rows, ([r.micro_batch for r in rows] if rows is not None else mbs)
+
+        rows_b, units_b = units_of(forward_only)
+        rows, units = units_of(micro_batches)
+        if rows is not None and recomputed_errors is not None:
+            recomputed_errors = join_per_row(recomputed_errors, rows)
+        return {"n_given": n_given, "inv_scale": inv_scale, "given_row": given_row, "forward_row": forward_row,
+                "rows_b": rows_b, "units_b": units_b, "rows": rows, "units": units,
+                "recomputed_errors": recomputed_errors, "ratio_type": loss_config.ratio_type}
+
+    def train_step(self, micro_batches: list[MicroBatch], loss_config: LossConfig, max_norm: float | None = 1.0,
+                   scheduler: Any = None, samples: int | None = None,
+                   recomputed_errors: list[Tensor] | None = None, join_tokens: int | None = None,
+                   skip_unscored: bool = True, prepared: dict[str, Any] | None = None,
+                   before_statistics: Any = None) -> Any:
+        """One optimizer step over this rank's micro-batches (src/prime_rl/trainer/rl/train.py:259-364);
+        same results and the same `StepResult` as `trainer.train_step`, micro-batches joined the same way and
+        fillers left out the same way (`trainer.scored`).  `prepared`: what `prepare_step` returned for these
+        micro-batches, if the caller has it already.  `before_statistics()` is called when the whole step has been
+        handed to the GPU, just before the host waits for the step's statistics: the place for host work that
+        can run beside the GPU (the trainer loads and prepares the next step's rollouts there)."""
+        from .trainer import (StepResult, attention_plan, add_ratio_statistics, forward, losses_per_given_row,
+                              ones_as_recomputed_error, restore_row_starts, scored_rows)
+
+        t0 = time.perf_counter()
+        if prepared is None:
+            prepared = self.prepare_step(micro_batches, loss_config, recomputed_errors, join_tokens, skip_unscored)
+        elif prepared["ratio_type"] != loss_config.ratio_type or prepared["n_given"] != len(micro_batches):
+            raise ValueError("train_step: `prepared` belongs to other micro-batches or another loss configuration")
+        n_given, inv_scale = prepared["n_given"], prepared["inv_scale"]
+        given_row, forward_row = prepared["given_row"], prepared["forward_row"]
+        rows_b, units_b, rows, units = prepared["rows_b"], prepared["units_b"], prepared["rows"], prepared["units"]
+        recomputed_errors = prepared["recomputed_errors"]
+        self._starts_sums = not self.graphs
         self._scale.fill_(inv_scale)
         tensors = Tensors()
         vocab = int(self.model.config.vocab_size)
         loss_parts: list[Tensor] = []
         loss_rows: list[int] = []
         state = {"tokens": 0, "passes": 0}
-
-        def units_of(mbs: list[MicroBatch]) -> tuple[list[Any] | None, list[MicroBatch]]:
-            rows = join_micro_batches(mbs, join_tokens) if token_mode and join_tokens > 0 else None
-            return rows, ([r.micro_batch for r in rows] if rows is not None else mbs)
 
         def book(joined: Any, mb: dict[str, Any], loss: Tensor, aux: dict[str, Tensor], came_from: list[int],
                  error: Tensor | None) -> None:
@@ -762,7 +792,6 @@ class Replica:
             return came_from[at : at + n], n
 
         # forward only first, so that the last pass of the step is the one the exchange hangs on
-        rows_b, units_b = units_of(forward_only)
         for k, host_mb in enumerate(units_b):
             mb = to_device(host_mb, self.device)
             plan = attention_plan(host_mb, self.device)
@@ -775,9 +804,6 @@ class Replica:
                 del logits
             book(rows_b[k] if rows_b is not None else None, mb, loss, aux, pieces_of(rows_b, k, forward_row)[0], None)
 
-        rows, units = units_of(micro_batches)
-        if rows is not None and recomputed_errors is not None:
-            recomputed_errors = join_per_row(recomputed_errors, rows)
         grad_norm = None
         for step_idx, host_mb in enumerate(units):
             mb = to_device(host_mb, self.device)
@@ -812,6 +838,8 @@ class Replica:
                                                gathers_in_flight=self.overlap)
         if scheduler is not None:
             scheduler.step()
+        if before_statistics is not None:
+            before_statistics()
         stats = tensors.compute_stats()
         if recomputed_errors is None:
             ones_as_recomputed_error(stats)

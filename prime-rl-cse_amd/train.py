@@ -218,6 +218,7 @@ def _train(config: RLTrainerConfig, world: Any, device: torch.device, mesh: Any)
     device_name = perf.describe_device(device)
     counter = None
     history: list[dict[str, float]] = []
+    ahead: list[tuple[list[Any], Any]] = []  # at most one entry: the next step's rollouts and their passes
     step = 0
     while config.max_steps is None or step < config.max_steps:
         if step in (0, 2):  # after the set-up, and once more when the first steps have filled every cache
@@ -233,12 +234,17 @@ def _train(config: RLTrainerConfig, world: Any, device: torch.device, mesh: Any)
             t_save = time.perf_counter() - t0
         if logprob_model is not None:
             snapshots[step] = {k: v.detach().clone() for k, v in model.state_dict().items()}
-        t0 = time.perf_counter()
-        loader.wait_for_batch()
-        t_wait = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        micro_batches = loader.get_batch()
-        t_data = time.perf_counter() - t0
+        prepared = None
+        if ahead:  # loaded and sorted while the last step's kernels were running
+            micro_batches, prepared = ahead.pop()
+            t_wait = t_data = 0.0
+        else:
+            t0 = time.perf_counter()
+            loader.wait_for_batch()
+            t_wait = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            micro_batches = loader.get_batch()
+            t_data = time.perf_counter() - t0
         t_recompute = 0.0
         errors = None
         if logprob_model is not None:
@@ -253,8 +259,18 @@ def _train(config: RLTrainerConfig, world: Any, device: torch.device, mesh: Any)
         samples = (config.data.fake.batch_size // world.world_size) if config.data.fake else None
         lr = optimizer.param_groups[0]["lr"]  # the rate this step is taken with (the scheduler moves on inside)
         if replica is not None:
+            more = config.max_steps is None or step + 1 < config.max_steps
+
+            def load_ahead() -> None:
+                # The step has been handed to the GPU and the host is about to wait for its statistics: if the
+                # next step's rollouts are there already (the orchestrator runs ahead of the trainer,
+                # `async_level`), they are read and sorted into passes now instead of with the GPU waiting.
+                if more and logprob_model is None and loader.ready():
+                    nxt = loader.get_batch()
+                    ahead.append((nxt, replica.prepare_step(nxt, config.loss)))
+
             res = replica.train_step(micro_batches, config.loss, config.optim.max_norm, scheduler, samples=samples,
-                                     recomputed_errors=errors)
+                                     recomputed_errors=errors, prepared=prepared, before_statistics=load_ahead)
         else:
             res = T.train_step(model, optimizer, micro_batches, config.loss, config.optim.max_norm, device, scheduler,
                                samples=samples, recomputed_errors=errors)

@@ -590,3 +590,36 @@ def test_a_step_with_nothing_to_learn_from_leaves_the_weights_to_weight_decay(mo
     assert res.passes == 1 and res.grad_norm == 0.0 and res.stats["loss/mean"] == 0.0
     assert res.stats["entropy/mean"] > 0.0 and res.stats["probs/mean"] > 0.0
     torch.testing.assert_close(rep.state.master.detach(), before, rtol=0, atol=0)
+
+
+def test_a_step_prepared_ahead_is_the_step_prepared_on_the_spot(monkeypatch):
+    """`prepare_step` is the host's share of `train_step`; done ahead (the trainer does it for step N + 1 from
+    the hook that runs while step N's kernels finish) it gives the same steps, bit for bit."""
+    from prime_rl_cse_amd.optim import FlatAdamW
+
+    monkeypatch.setenv("PRL_SPLIT_NO_GRADIENT", "1")
+    gen = torch.Generator().manual_seed(53)
+    batches = [_rollout_rows(gen, 4, 4096, [(0, 1), (1, 0), (1, 1), (1, 2), (1, 3), (2, 2)]) for _ in range(3)]
+    loss_cfg = prl.LossConfig()
+    outs = []
+    for ahead in (False, True):
+        model = T.get_model(tiny_config(vocab=4096), DEV, torch.float32, seed=11)
+        rep = Replica(model, lambda m: FlatAdamW(m.parameters(), lr=1e-3, weight_decay=0.01),
+                      compute_dtype=torch.float32)
+        mine = copy.deepcopy(batches)
+        out, calls, queue = [], [], []
+        for i, mbs in enumerate(mine):
+            def hook(i=i):
+                calls.append(i)
+                if ahead and i + 1 < len(mine):
+                    queue.append(rep.prepare_step(mine[i + 1], loss_cfg))
+            prepared = queue.pop() if queue else None
+            res = rep.train_step(mbs, loss_cfg, max_norm=1.0, prepared=prepared, before_statistics=hook)
+            out.append((res, rep.state.master.detach().clone()))
+        assert calls == [0, 1, 2]
+        outs.append(out)
+    for (r0, m0), (r1, m1) in zip(*outs):
+        assert r0.stats == r1.stats and r0.grad_norm == r1.grad_norm and (r0.passes, r0.tokens) == (r1.passes, r1.tokens)
+        assert torch.equal(m0, m1)
+    with pytest.raises(ValueError, match="prepared"):
+        rep.train_step(batches[0][:2], loss_cfg, prepared=rep.prepare_step(batches[0], loss_cfg))
