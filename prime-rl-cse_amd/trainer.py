@@ -300,6 +300,19 @@ GATHER_MULTIPLE = 256  # the number of gathered rows is rounded up to a multiple
 GATHER_AT_MOST = 0.9  # gather only when at most this share of a row's positions is left
 
 
+def gather_rule(tokens: int, hidden: int) -> tuple[int, float]:
+    """(multiple the number of gathered rows is rounded up to, largest share of a row's positions worth gathering).
+
+    Long rows of narrow models get a coarser rule.  The LM head's input gradient, [R, V] x [V, H], has few output
+    tiles and a very long sum; with H = 1024 or 2048 the GEMM library serves it at 1.2-1.3 PFLOP/s when R is
+    8192, 10240, 12288 or 16384 and at 0.6-0.9 at every other multiple of 256 (14336 included), so that 11776 rows
+    cost more than 12288 and 14336 as much as 16384 (`tools/lm_head_rows_sweep.py`); with H = 3584 the cost follows
+    R at every size."""
+    if tokens > 8192 and 0 < hidden <= 2048:
+        return 2048, 0.76
+    return GATHER_MULTIPLE, GATHER_AT_MOST
+
+
 def scored_rows(host_micro_batch: MicroBatch, loss_config: LossConfig, model: nn.Module,
                 device: torch.device | str) -> Tensor | None:
     """The positions of a packed row at which the LM head has to run, on the device, or None for "all of them".
@@ -315,8 +328,8 @@ def scored_rows(host_micro_batch: MicroBatch, loss_config: LossConfig, model: nn
     Only in token mode (with one ratio per sample the reference logs unmasked samples' ratios too), for a model
     that computes bf16 logits over a vocabulary the one-pass row kernel handles, and only when at most
     `GATHER_AT_MOST` of the positions is left (the count is rounded up to a multiple of `GATHER_MULTIPLE` with
-    positions nobody scores, so that the LM head's products meet few distinct sizes).  PRL_GATHER_SCORED=0
-    switches it off."""
+    positions nobody scores, so that the LM head's products meet few distinct sizes; `gather_rule` has the
+    numbers for long rows of narrow models).  PRL_GATHER_SCORED=0 switches it off."""
     import os
 
     from . import _capi as C
@@ -336,11 +349,12 @@ def scored_rows(host_micro_batch: MicroBatch, loss_config: LossConfig, model: nn
         return None
     import numpy as np
 
+    multiple, at_most = gather_rule(int(mask.shape[1]), int(getattr(getattr(model, "config", None), "hidden_size", 0)))
     n_scored = int(np.count_nonzero(mask.numpy()[0, 1:]))  # (cheap, and settles the rows where every token is scored)
-    if n_scored == 0 or n_scored > GATHER_AT_MOST * (mask.shape[1] - 1):
+    if n_scored == 0 or n_scored > at_most * (mask.shape[1] - 1):
         return None
-    keep = scored_positions(mask, multiple=GATHER_MULTIPLE)
-    if keep.numel() > GATHER_AT_MOST * (mask.shape[1] - 1):
+    keep = scored_positions(mask, multiple=multiple)
+    if keep.numel() > at_most * (mask.shape[1] - 1):
         return None
     return host_to_device(keep, device, torch.int64)
 

@@ -204,6 +204,21 @@ def test_scored_rows_engage_only_where_they_apply(monkeypatch):
     most = {"loss_mask": torch.rand(1, t, generator=torch.Generator().manual_seed(0)) < 0.8}
     assert T.scored_rows(most, tok, model(torch.bfloat16, 151936), "cpu").numel() == 1792  # ~1640 -> 1792 of 2047
     assert T.scored_rows({"loss_mask": torch.zeros(1, t, dtype=torch.bool)}, tok, model(torch.bfloat16, 151936), "cpu") is None
+    # long rows of narrow models: multiples of 2048 rows, and only up to three quarters of the row
+    assert T.gather_rule(16384, 1024) == (2048, 0.76) and T.gather_rule(16384, 3584) == (256, 0.9)
+    assert T.gather_rule(8192, 1024) == (256, 0.9) and T.gather_rule(16384, 0) == (256, 0.9)
+    narrow = model(torch.bfloat16, 151936)
+    narrow.config.hidden_size = 1024
+    long_mask = torch.zeros(1, 16384, dtype=torch.bool)
+    long_mask[0, 1000:12000] = True  # 11000 scored tokens -> 12288 rows
+    assert T.scored_rows({"loss_mask": long_mask}, tok, narrow, "cpu").numel() == 12288
+    long_mask[0, 12000:13000] = True  # 12000 -> 12288 still
+    assert T.scored_rows({"loss_mask": long_mask}, tok, narrow, "cpu").numel() == 12288
+    long_mask[0, 13000:13400] = True  # 12400 would round up to 14336: the whole row instead
+    assert T.scored_rows({"loss_mask": long_mask}, tok, narrow, "cpu") is None
+    wide = model(torch.bfloat16, 152064)
+    wide.config.hidden_size = 3584
+    assert T.scored_rows({"loss_mask": long_mask}, tok, wide, "cpu").numel() == 12544  # 12400 -> a multiple of 256
     monkeypatch.setenv("PRL_GATHER_SCORED", "0")
     assert T.scored_rows(mb, tok, model(torch.bfloat16, 151936), "cpu") is None
 
