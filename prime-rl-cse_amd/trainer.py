@@ -379,7 +379,7 @@ def split_by_gradient(micro_batches: list[MicroBatch]
     Samples without any scored token are dropped.  Host tensors only.
 
     Worth it only where the passes are long enough to run at full rate either way: with 150 K tokens per step and
-    half of the problems settled a 0.6B step takes 0.43-0.54 s instead of 0.68-0.71 s, with 10 K tokens per step
+    half of the problems settled a 0.6B step takes 0.49 s instead of 0.71 s, with 10 K tokens per step
     (one short pass becoming two shorter ones, of lengths no product has met before) 0.051-0.058 s instead of
     0.051-0.053 s.  So by default rows are separated only when at least `SPLIT_MIN_FORWARD_TOKENS` tokens go
     forward-only out of at least `SPLIT_MIN_TOKENS`; PRL_SPLIT_NO_GRADIENT=1 separates always, =0 never."""
