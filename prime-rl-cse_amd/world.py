@@ -56,3 +56,9 @@ def reset_world() -> None:
     """Forget the cached World (tests change the environment between cases)."""
     global _current
     _current = None
+
+
+if __name__ == "__main__":
+    # under torchrun every rank prints where it sits (the reference runs its world.py the same way,
+    # tests/unit/train/test_world.py:39-52)
+    print(get_world())
