@@ -256,6 +256,46 @@ def test_trainer_entry_point_on_rollout_files(tmp_path, monkeypatch):
     assert (tmp_path / "weights" / "step_2" / "pytorch_model.bin").exists()
 
 
+def test_trainer_entry_point_on_the_reference_tests_dummy_batches(tmp_path, monkeypatch):
+    """The reference's trainer-path test with its own dummy data (tests/integration/test_trainer_path.py:18-82):
+    files written with plain torch.save in the orchestrator's layout, 16 samples of 16 tokens in micro-batches of
+    8, position ids that are ALL zero (attention then keeps every token to itself, the loss sees one sample per
+    row), then `trainer @ configs/debug/rl/train.toml --data.fake None`: five steps without an error."""
+    from prime_rl_cse_amd.settings import RLTrainerConfig, parse_argv
+    from prime_rl_cse_amd.train import train
+
+    _single_rank_env(monkeypatch, 29764)
+    gen = torch.Generator().manual_seed(11)
+    steps, batch_size, micro_batch_size, seq_len = 5, 16, 8, 16
+    for step in range(steps):
+        batches = []
+        for _ in range(batch_size // micro_batch_size):
+            n = micro_batch_size * seq_len
+            batches.append({
+                "input_ids": torch.randint(0, 100, (1, n), generator=gen),
+                "position_ids": torch.zeros(1, n, dtype=torch.long),
+                "advantages": torch.randn(1, n, generator=gen),
+                "loss_mask": torch.ones(1, n, dtype=torch.bool),
+                "logprobs": torch.randn(1, n, generator=gen),
+                "temperature": 1.0,
+                "total_tokens": n,
+            })
+        step_dir = tmp_path / "rollouts" / f"step_{step}"
+        step_dir.mkdir(parents=True)
+        torch.save(batches, step_dir / "rank_0.tmp")
+        (step_dir / "rank_0.tmp").rename(step_dir / "rank_0.pt")
+    toml = tmp_path / "train.toml"  # configs/debug/rl/train.toml of the reference
+    toml.write_text("max_steps = 5\nasync_level = 5\n\n[data.fake]\nbatch_size = 16\nmicro_batch_size = 1\nseq_len = 128\n")
+    cfg = parse_argv(RLTrainerConfig, ["@", str(toml), "--output-dir", str(tmp_path), "--data.fake", "None",
+                                       "--log.level", "debug", "--model.debug.num-layers", "2"], use_env=False)
+    assert cfg.data.fake is None
+    history = train(cfg)
+    assert len(history) == steps
+    for h in history:
+        assert h["optim/grad_norm"] > 0 and h["loss/mean"] == h["loss/mean"]  # finite, not NaN
+        assert h["entropy/mean"] > 0
+
+
 def test_rollout_files_through_both_trainers_agree(tmp_path, monkeypatch):
     """Ragged rollouts (prompts masked, completions of many lengths, several rows per step) from
     `rollouts/step_N/rank_0.pt` through the FSDP2 trainer and through the whole-model trainer, fused
