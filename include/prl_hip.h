@@ -496,6 +496,33 @@ int prl_qk_norm_rope_bwd(const void* gq, const int64_t* gq_strides, const void* 
                          int64_t k_heads, void* stream);
 
 /*
+ * The three matrix products of the LM head, hand-written for the MFMA units (bf16 in, fp32 accumulation, bf16
+ * out).  They replace the final projection of the model's forward (src/prime_rl/trainer/model.py:251-254, whose
+ * logits src/prime_rl/trainer/rl/train.py:285 picks up) and the two products autograd runs for it behind
+ * loss.backward() (src/prime_rl/trainer/rl/train.py:310), which the reference leaves to its BLAS library:
+ *     prl_lm_head_fwd         logits[T, V]  = hidden[T, H] . weight[V, H]^T
+ *     prl_lm_head_bwd_input   dhidden[T, H] = dlogits[T, V] . weight[V, H]
+ *     prl_lm_head_bwd_weight  dweight[V, H] = dlogits[T, V]^T . hidden[T, H]
+ * Every matrix is row-major bf16 with `*_stride` ELEMENTS between rows (multiples of 8; outputs multiples of 4),
+ * 16-byte aligned.  T, H and V must be multiples of 64 (prl_lm_head_supported); rows or columns beyond a multiple
+ * of 256 are handled inside the kernels.  Sums run in fp32 in the order of the K index within a 64-wide step and
+ * over the steps front to back; a product whose K is split over workgroups (dhidden with few rows) adds its fp32
+ * partial results in split order, so results are reproducible run to run.
+ * workspace: prl_lm_head_workspace_bytes(T, H, V) bytes of device scratch, 16-byte aligned, needed by the two
+ * backward products (fp32 partial results of a K split; hidden^T); the forward needs none.
+ */
+int prl_lm_head_supported(int dtype, int64_t T, int64_t H, int64_t V);
+size_t prl_lm_head_workspace_bytes(int64_t T, int64_t H, int64_t V);
+int prl_lm_head_fwd(const void* hidden, int64_t hidden_stride, const void* weight, int64_t weight_stride,
+                    void* logits, int64_t logits_stride, int64_t T, int64_t H, int64_t V, void* stream);
+int prl_lm_head_bwd_input(const void* dlogits, int64_t dlogits_stride, const void* weight, int64_t weight_stride,
+                          void* dhidden, int64_t dhidden_stride, int64_t T, int64_t H, int64_t V, void* workspace,
+                          size_t workspace_bytes, void* stream);
+int prl_lm_head_bwd_weight(const void* dlogits, int64_t dlogits_stride, const void* hidden, int64_t hidden_stride,
+                           void* dweight, int64_t dweight_stride, int64_t T, int64_t H, int64_t V, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
+/*
  * Number of nodes of a captured HIP graph (`graph` is a hipGraph_t, child graphs included) and how many of them
  * are memset nodes.  No counterpart in the reference, which never captures graphs
  * (src/prime_rl/trainer/model.py:219-230 hands the blocks to a tracing compiler instead): the whole-model

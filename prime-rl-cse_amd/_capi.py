@@ -180,6 +180,22 @@ SIGNATURES = {
          c_int, c_int64, c_int64, c_void_p, c_size_t, c_void_p],
     ),
     "prl_sum_parts": (c_int, [c_void_p, c_int, c_int64, c_int32, c_int64, c_void_p, c_void_p]),
+    "prl_lm_head_supported": (c_int, [c_int, c_int64, c_int64, c_int64]),
+    "prl_lm_head_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
+    "prl_lm_head_fwd": (
+        c_int,
+        [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p],
+    ),
+    "prl_lm_head_bwd_input": (
+        c_int,
+        [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_size_t,
+         c_void_p],
+    ),
+    "prl_lm_head_bwd_weight": (
+        c_int,
+        [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_size_t,
+         c_void_p],
+    ),
     "prl_graph_node_counts": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64)]),
     "prl_group_advantage": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "prl_stats_workspace_bytes": (c_size_t, [c_int]),

@@ -1,0 +1,524 @@
+// The three products of the LM head (src/prime_rl/trainer/model.py:251-254 forward, autograd's two products behind
+// src/prime_rl/trainer/rl/train.py:310) as hand-written bf16 MFMA kernels for gfx950:
+//     logits[T, V]  = hidden[T, H] . weight[V, H]^T
+//     dhidden[T, H] = dlogits[T, V] . weight[V, H]
+//     dweight[V, H] = dlogits[T, V]^T . hidden[T, H]
+// One kernel template serves all three.  It computes C = P . Q for a "K-major" P ([M][K], K contiguous) and a Q
+// that is either K-major ([N][K]) or "MN-major" ([K][N], N contiguous, fragments through the transposing LDS
+// read), and stores C, C^T or an fp32 partial slab of a K split:
+//     forward:  P = hidden,   Q = weight  (K-major, K = H),  C = logits
+//     dhidden:  P = dlogits,  Q = weight  (MN-major, K = V), C = dhidden (fp32 slabs summed afterwards when K is split)
+//     dweight:  P = hidden^T, Q = dlogits (MN-major, K = T), C^T = dweight (hidden^T is made by a small transpose)
+//
+// Structure of a workgroup: a 256 x 256 tile of C, K walked in tiles of 64, 8 waves as 2 (rows) x 4 (columns), each
+// wave 128 x 64 of C in 32 accumulator tiles of v_mfma_f32_16x16x32_bf16.  A K-tile's operands (2 x 32 KB) come into
+// one of two LDS stages by direct-to-LDS loads (no registers on the way); the LDS images are XOR-swizzled through the
+// per-lane SOURCE address so that the 16-byte row reads and the transposing reads are free of bank conflicts.  A
+// K-tile is four phases (one 64 x 32 quadrant of the wave's output each, 16 MFMAs); a phase is a load section (LDS
+// reads for this phase, direct-to-LDS loads for the next K-tile) and an MFMA section, separated by barriers, and the
+// two waves that share a SIMD run one section apart, so that one computes while the other loads.
+#include "prl_common.h"
+
+namespace prl {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+
+constexpr int kBM = 256, kBN = 256, kBK = 64;
+constexpr int kGemmThreads = 512;
+constexpr int kQuarterBytes = 16384;         // 128 rows x 64 k, or 64 k x 128 columns, of bf16
+constexpr int kStageBytes = 4 * kQuarterBytes;  // P half 0 | P half 1 | Q half 0 | Q half 1
+constexpr int kSuperM = 8, kSuperN = 4;      // tiles of C that one XCD's 32 compute units work on together
+
+enum { kOutBf16 = 0, kOutF32Slab = 1, kOutBf16Transposed = 2 };
+
+struct GemmArgs {
+  const uint16_t* P;  // [M][K], ldp elements between rows
+  const uint16_t* Q;  // K-major: [N][K]; MN-major: [K][N]; ldq elements between rows
+  void* C;            // bf16 [M][N] (ldc), bf16 [N][M] (ldc, transposed store) or fp32 [nsplit][M][N] (ldc = N)
+  int64_t ldp, ldq, ldc;
+  int64_t slab_stride;  // elements between the fp32 slabs of two K splits
+  int M, N;
+  int ktiles;            // K / 64
+  int ktiles_per_split;  // K-tiles one workgroup walks
+  int nsplit;
+  int mtiles, ntiles;  // ceil(M / 256), ceil(N / 256)
+  int super_m, super_n;  // ceil(mtiles / 8), ceil(ntiles / 4)
+};
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* global_void_ptr;
+
+__device__ __forceinline__ void glds16(const uint16_t* src, char* lds_wave_base) {
+  // 16 bytes per lane from `src` (per lane) to lds_wave_base + 16 * lane (the base is the same in every lane)
+  __builtin_amdgcn_global_load_lds((global_void_ptr)src, (lds_void_ptr)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ bf16x8 lds_frag(const char* p) {
+  return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
+}
+// One transposing LDS read: a 16-lane group gets a block of 4 rows x 16 columns of 16-bit elements column-major;
+// lane 4q + p of the group supplies the address of row q, columns 4p .. 4p + 3, lane i receives column i of the 4
+// rows.  Written as inline assembly on purpose: the compiler treats the builtin for this instruction as a possible
+// LDS store and puts a full `s_waitcnt vmcnt(0)` between a direct-to-LDS load in flight and the read, which would
+// drain the prefetch in every phase.  An asm load is not counted by the compiler, so `wait_tr_reads` below must stand
+// between these reads and the first use of their results.
+template <int OFF>
+__device__ __forceinline__ u32x2_t lds_read_tr(unsigned lds_addr) {
+  u32x2_t r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "n"(OFF) : "memory");
+  return r;
+}
+struct QFrag {  // one 16 x 32 operand fragment as its two 8-byte halves (k 0-3 and 4-7 of the lane's eight)
+  u32x2_t lo, hi;
+};
+__device__ __forceinline__ bf16x8 as_bf16x8(const QFrag& f) {
+  const u32x4 v = {f.lo.x, f.lo.y, f.hi.x, f.hi.y};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// Which tile and K split a workgroup of the 1-D grid takes.  Workgroup b runs on XCD b % 8; an XCD's 32 compute
+// units take one "super-tile" of 8 x 4 tiles of C of one K split at a time, so that the operand panels they share
+// are read from memory once and from that XCD's L2 afterwards.
+__device__ __forceinline__ bool gemm_item(const GemmArgs& a, int& mt, int& nt, int& split) {
+  const int id = (int)blockIdx.x, xcd = id & 7, slot = id >> 3;
+  const int sid = (slot >> 5) * 8 + xcd, within = slot & 31;
+  const int per_split = a.super_m * a.super_n;
+  if (sid >= per_split * a.nsplit) return false;
+  split = sid / per_split;
+  const int s = sid - split * per_split;
+  const int sm = s % a.super_m, sn = s / a.super_m;
+  mt = sm * kSuperM + (within & (kSuperM - 1));
+  nt = sn * kSuperN + (within >> 3);
+  return mt < a.mtiles && nt < a.ntiles;
+}
+
+template <bool Q_KMAJOR, int OUT>
+__global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * kStageBytes];
+
+  int mt, nt, split;
+  if (!gemm_item(a, mt, nt, split)) return;
+  const int kt0 = split * a.ktiles_per_split;
+  int nk = a.ktiles - kt0;
+  if (nk > a.ktiles_per_split) nk = a.ktiles_per_split;
+  if (nk <= 0) return;
+
+  const int tid = (int)threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 2, wc = wid & 3;
+  const int m0 = mt * kBM, n0 = nt * kBN;
+
+  // ---- staging: per thread four 16-byte pieces of P and four of Q per K-tile
+  // P (and a K-major Q): the quarter is [128 rows][64 k] with 128-byte rows; LDS slot (16 bytes) s = row * 8 + chunk
+  // holds the row's chunk  chunk ^ ((row >> 1) & 7).
+  const uint16_t* psrc[4];
+  const uint16_t* qsrc[4];
+  {
+    const int chunk = (tid & 7) ^ ((tid >> 4) & 7);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // j = 2 * half + i
+      int row = m0 + 64 * j + (tid >> 3);
+      if (row > a.M - 1) row = a.M - 1;
+      psrc[j] = a.P + (int64_t)row * a.ldp + (int64_t)kt0 * kBK + 8 * chunk;
+    }
+    if (Q_KMAJOR) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int row = n0 + 64 * j + (tid >> 3);
+        if (row > a.N - 1) row = a.N - 1;
+        qsrc[j] = a.Q + (int64_t)row * a.ldq + (int64_t)kt0 * kBK + 8 * chunk;
+      }
+    } else {
+      // the quarter is [64 k][128 columns] with 256-byte rows; slot s = krow * 16 + chunk holds the row's chunk
+      // chunk ^ (f(krow) << 1),  f(krow) = (krow & 3) | (((krow >> 3) & 1) << 2)
+      const int krow = tid >> 4;
+      const int f = (krow & 3) | (((krow >> 3) & 1) << 2);
+      const int ch = (tid & 15) ^ (f << 1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {  // j = 2 * half + i; piece i holds k rows 32 i .. 32 i + 31
+        int col = n0 + 128 * (j >> 1) + 8 * ch;
+        if (col > a.N - 8) col = a.N - 8;
+        qsrc[j] = a.Q + ((int64_t)kt0 * kBK + 32 * (j & 1) + krow) * a.ldq + col;
+      }
+    }
+  }
+  const int64_t pstep = kBK, qstep = Q_KMAJOR ? (int64_t)kBK : (int64_t)kBK * a.ldq;
+  // LDS destination of piece j of this wave inside a stage (the hardware adds 16 * lane)
+  char* const wave_dst = smem + wid * 1024;
+
+  auto stage_p = [&](int stage) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      glds16(psrc[j], wave_dst + stage * kStageBytes + j * 8192);
+      psrc[j] += pstep;
+    }
+  };
+  auto stage_q = [&](int stage) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      glds16(qsrc[j], wave_dst + stage * kStageBytes + 2 * kQuarterBytes + j * 8192);
+      qsrc[j] += qstep;
+    }
+  };
+
+  // ---- fragment addresses (bytes inside a stage)
+  // P rows of this wave are the half `wr`; row tile rt adds 2048, k step ks flips bit 6 of the offset
+  const int sw = (lane >> 1) & 7;
+  const int p_off = wr * kQuarterBytes + (lane & 15) * 128 + (((lane >> 4)) ^ sw) * 16;
+  int q_off[4];
+  if (Q_KMAJOR) {
+    q_off[0] = 2 * kQuarterBytes + (wc >> 1) * kQuarterBytes + ((wc & 1) * 64 + (lane & 15)) * 128 +
+               (((lane >> 4)) ^ sw) * 16;
+    q_off[1] = q_off[2] = q_off[3] = 0;
+  } else {
+    const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+    const int f = qq | ((g & 1) << 2);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+      q_off[ct] = 2 * kQuarterBytes + (wc >> 1) * kQuarterBytes + (8 * g + qq) * 256 +
+                  (((4 * (wc & 1) + ct) ^ f) * 32) + 8 * pp;
+  }
+  auto p_frag = [&](int stage, int rt, int ks) -> bf16x8 {
+    return lds_frag(smem + stage * kStageBytes + (p_off ^ (ks * 64)) + rt * 2048);
+  };
+  const unsigned smem_addr = (unsigned)(uintptr_t)(lds_void_ptr)smem;
+  auto q_frag_k = [&](int stage, int ct, int ks) -> QFrag {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(smem + stage * kStageBytes + (q_off[0] ^ (ks * 64)) + ct * 2048);
+    QFrag f;
+    f.lo = (u32x2_t){v.x, v.y};
+    f.hi = (u32x2_t){v.z, v.w};
+    return f;
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  bf16x8 af[4][2];     // the 64 rows of P this phase multiplies: row tiles 4 h .. 4 h + 3
+  QFrag bx[2][2];      // Q columns 0 .. 31 of the wave (column tiles 0, 1)
+  QFrag by[2][2];      // Q columns 32 .. 63 (column tiles 2, 3)
+
+  auto load_a = [&](int stage, int h) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) af[r][ks] = p_frag(stage, 4 * h + r, ks);
+  };
+  // column tiles 2 hb, 2 hb + 1 of the wave's Q columns into b
+  auto load_b = [&](int stage, int hb, QFrag (&b)[2][2]) {
+    if (Q_KMAJOR) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) b[c][ks] = q_frag_k(stage, 2 * hb + c, ks);
+    } else {
+      const unsigned base = smem_addr + stage * kStageBytes;
+      const unsigned a0 = base + q_off[2 * hb], a1 = base + q_off[2 * hb + 1];
+      b[0][0].lo = lds_read_tr<0>(a0);
+      b[0][0].hi = lds_read_tr<1024>(a0);
+      b[0][1].lo = lds_read_tr<8192>(a0);
+      b[0][1].hi = lds_read_tr<8192 + 1024>(a0);
+      b[1][0].lo = lds_read_tr<0>(a1);
+      b[1][0].hi = lds_read_tr<1024>(a1);
+      b[1][1].lo = lds_read_tr<8192>(a1);
+      b[1][1].hi = lds_read_tr<8192 + 1024>(a1);
+    }
+  };
+  // behind the barrier that follows a load_b: the asm reads have landed before anything uses them
+  auto wait_tr_reads = [&](QFrag (&b)[2][2]) {
+    if (!Q_KMAJOR) {
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(b[0][0].lo), "+v"(b[0][0].hi), "+v"(b[0][1].lo), "+v"(b[0][1].hi), "+v"(b[1][0].lo),
+                     "+v"(b[1][0].hi), "+v"(b[1][1].lo), "+v"(b[1][1].hi)
+                   :
+                   : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // 16 MFMAs: rows 4 h .. 4 h + 3 against column tiles 2 hb, 2 hb + 1.  The operand that runs along the lanes of
+  // the result is the one whose index is contiguous in the stored matrix.
+  auto mma = [&](int h, int hb, const QFrag (&b)[2][2]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          f32x4& d = acc[4 * h + r][2 * hb + c];
+          const bf16x8 q = as_bf16x8(b[c][ks]);
+          d = OUT == kOutBf16Transposed ? mfma16(af[r][ks], q, d) : mfma16(q, af[r][ks], d);
+        }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto bar = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue: K-tile 0 into stage 0
+  stage_p(0);
+  stage_q(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  bar();
+  load_b(0, 0, bx);
+  wait_tr_reads(bx);
+  if (wid >= 4) bar();  // waves 4-7 run one section behind waves 0-3
+
+  // One K-tile.  EVEN tiles multiply in the order (a0, bx) (a0, by) (a1, by) (a1, bx) and leave with the next
+  // tile's by loaded; odd tiles (a0, by) (a0, bx) (a1, bx) (a1, by) and leave with the next tile's bx loaded.
+  // The next K-tile's direct-to-LDS loads are issued in the first two load sections and waited for at the end of
+  // the third; the barrier behind that wait orders them for every wave's reads from the fourth section on.  The
+  // stage they overwrite was last read two K-tile phases earlier.  The fourth section's reads (asm, not counted by
+  // the compiler) are waited for behind that phase's MFMAs, so their registers are final before the loop's
+  // back-edge, where the compiler may copy them.
+#define PRL_GEMM_TILE(EVEN)                                                         \
+  {                                                                                 \
+    const int st = (EVEN) ? 0 : 1;                                                  \
+    const bool has_next = t + 1 < nk;                                               \
+    if (has_next) stage_p(st ^ 1);                                                  \
+    load_a(st, 0);                                                                  \
+    bar();                                                                          \
+    if (EVEN) mma(0, 0, bx); else mma(0, 1, by);                                    \
+    bar();                                                                          \
+    if (has_next) stage_q(st ^ 1);                                                  \
+    if (EVEN) load_b(st, 1, by); else load_b(st, 0, bx);                            \
+    bar();                                                                          \
+    if (EVEN) { wait_tr_reads(by); mma(0, 1, by); } else { wait_tr_reads(bx); mma(0, 0, bx); } \
+    bar();                                                                          \
+    load_a(st, 1);                                                                  \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                \
+    bar();                                                                          \
+    if (EVEN) mma(1, 1, by); else mma(1, 0, bx);                                    \
+    bar();                                                                          \
+    if (has_next) { if (EVEN) load_b(st ^ 1, 1, by); else load_b(st ^ 1, 0, bx); }  \
+    bar();                                                                          \
+    if (EVEN) mma(1, 0, bx); else mma(1, 1, by);                                    \
+    if (has_next) { if (EVEN) wait_tr_reads(by); else wait_tr_reads(bx); }          \
+    bar();                                                                          \
+  }
+
+  for (int t = 0; t < nk; t += 2) {
+    PRL_GEMM_TILE(true)
+    ++t;
+    if (t >= nk) break;
+    PRL_GEMM_TILE(false)
+    --t;
+  }
+#undef PRL_GEMM_TILE
+  if (wid < 4) bar();
+
+  // ---- epilogue: every lane holds, per accumulator tile, 4 consecutive elements along the contiguous index
+  const int lr = lane & 15, lq = lane >> 4;
+  if (OUT == kOutBf16Transposed) {
+    uint16_t* C = reinterpret_cast<uint16_t*>(a.C);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const int n = n0 + wc * 64 + 16 * ct + lr;
+#pragma unroll
+      for (int rt = 0; rt < 8; ++rt) {
+        const int m = m0 + wr * 128 + 16 * rt + 4 * lq;
+        if (n < a.N && m < a.M) {
+          const f32x4 v = acc[rt][ct];
+          u32x2_t o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+          *reinterpret_cast<u32x2_t*>(C + (int64_t)n * a.ldc + m) = o;
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int rt = 0; rt < 8; ++rt) {
+      const int m = m0 + wr * 128 + 16 * rt + lr;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const int n = n0 + wc * 64 + 16 * ct + 4 * lq;
+        if (m < a.M && n < a.N) {
+          const f32x4 v = acc[rt][ct];
+          if (OUT == kOutF32Slab) {
+            float* C = reinterpret_cast<float*>(a.C) + (int64_t)split * a.slab_stride;
+            *reinterpret_cast<f32x4*>(C + (int64_t)m * a.ldc + n) = v;
+          } else {
+            uint16_t* C = reinterpret_cast<uint16_t*>(a.C);
+            u32x2_t o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+            *reinterpret_cast<u32x2_t*>(C + (int64_t)m * a.ldc + n) = o;
+          }
+        }
+      }
+    }
+  }
+}
+
+// out[c][r] = in[r][c] for a bf16 [rows][cols] matrix: 64 x 64 blocks through LDS, 16-byte loads and stores.
+__global__ void __launch_bounds__(256) k_transpose_bf16(const uint16_t* __restrict__ in, int64_t ld_in,
+                                                       uint16_t* __restrict__ out, int64_t ld_out, int rows, int cols) {
+  __shared__ uint16_t tile[64][72];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int id = it * 256 + tid, r = id >> 3, ch = id & 7;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (r0 + r < rows && c0 + 8 * ch < cols)
+      v = *reinterpret_cast<const u32x4*>(in + (int64_t)(r0 + r) * ld_in + c0 + 8 * ch);
+    *reinterpret_cast<u32x4*>(&tile[r][8 * ch]) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int id = it * 256 + tid, c = id >> 3, ch = id & 7;
+    if (c0 + c < cols && r0 + 8 * ch < rows) {
+      uint16_t e[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = tile[8 * ch + j][c];
+      u32x4 v = {(uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16),
+                 (uint32_t)e[4] | ((uint32_t)e[5] << 16), (uint32_t)e[6] | ((uint32_t)e[7] << 16)};
+      *reinterpret_cast<u32x4*>(out + (int64_t)(c0 + c) * ld_out + r0 + 8 * ch) = v;
+    }
+  }
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+static GemmArgs make_args(const void* P, int64_t ldp, const void* Q, int64_t ldq, void* C, int64_t ldc, int64_t M,
+                          int64_t N, int64_t K, int nsplit) {
+  GemmArgs a;
+  a.P = reinterpret_cast<const uint16_t*>(P);
+  a.Q = reinterpret_cast<const uint16_t*>(Q);
+  a.C = C;
+  a.ldp = ldp;
+  a.ldq = ldq;
+  a.ldc = ldc;
+  a.slab_stride = M * N;
+  a.M = (int)M;
+  a.N = (int)N;
+  a.ktiles = (int)(K / kBK);
+  a.ktiles_per_split = (a.ktiles + nsplit - 1) / nsplit;
+  a.nsplit = (a.ktiles + a.ktiles_per_split - 1) / a.ktiles_per_split;  // no split without a K-tile
+  a.mtiles = (int)((M + kBM - 1) / kBM);
+  a.ntiles = (int)((N + kBN - 1) / kBN);
+  a.super_m = (a.mtiles + kSuperM - 1) / kSuperM;
+  a.super_n = (a.ntiles + kSuperN - 1) / kSuperN;
+  return a;
+}
+static unsigned gemm_grid(const GemmArgs& a) {
+  const int supers = a.super_m * a.super_n * a.nsplit;
+  return 8u * 32u * (unsigned)((supers + 7) / 8);
+}
+
+// K splits for the input-gradient product: few tiles of C, a very long K.  Enough splits that the chip's 256
+// compute units all have a tile, none when the tiles alone fill it.
+static int dx_splits(int64_t T, int64_t H, int64_t V) {
+  const int64_t tiles = ((T + kBM - 1) / kBM) * ((H + kBN - 1) / kBN);
+  if (tiles >= 224) return 1;
+  int64_t s = (256 + tiles - 1) / tiles;
+  const int64_t ktiles = V / kBK;
+  if (s > 16) s = 16;
+  if (s > ktiles) s = ktiles;
+  return (int)s;
+}
+
+}  // namespace prl
+
+using namespace prl;
+
+extern "C" int prl_lm_head_supported(int dtype, int64_t T, int64_t H, int64_t V) {
+  return dtype == PRL_BF16 && T >= 1 && H >= kBK && V >= 8 && H % kBK == 0 && V % kBK == 0 && T % kBK == 0 &&
+         T < (1 << 30) && V < (1 << 30) && H < (1 << 30);
+}
+
+extern "C" size_t prl_lm_head_workspace_bytes(int64_t T, int64_t H, int64_t V) {
+  if (T <= 0 || H <= 0 || V <= 0) return 0;
+  const int s = dx_splits(T, H, V);
+  const size_t slabs = s > 1 ? (size_t)s * (size_t)T * (size_t)H * sizeof(float) : 0;
+  const size_t xt = (size_t)T * (size_t)H * sizeof(uint16_t);
+  return slabs > xt ? slabs : xt;
+}
+
+extern "C" int prl_lm_head_fwd(const void* hidden, int64_t hidden_stride, const void* weight, int64_t weight_stride,
+                               void* logits, int64_t logits_stride, int64_t T, int64_t H, int64_t V, void* stream) {
+  clear_error();
+  PRL_REQUIRE(hidden && weight && logits, "prl_lm_head_fwd: null pointer");
+  PRL_REQUIRE(prl_lm_head_supported(PRL_BF16, T, H, V), "prl_lm_head_fwd: unsupported shape T=%lld H=%lld V=%lld",
+              (long long)T, (long long)H, (long long)V);
+  PRL_REQUIRE(aligned16(hidden) && aligned16(weight) && aligned16(logits) && hidden_stride % 8 == 0 &&
+                  weight_stride % 8 == 0 && logits_stride % 4 == 0 && hidden_stride >= H && weight_stride >= H &&
+                  logits_stride >= V,
+              "prl_lm_head_fwd: pointers must be 16-byte aligned and row strides multiples of 8 elements");
+  const GemmArgs a = make_args(hidden, hidden_stride, weight, weight_stride, logits, logits_stride, T, V, H, 1);
+  hipLaunchKernelGGL((k_lm_gemm<true, kOutBf16>), dim3(gemm_grid(a)), dim3(kGemmThreads), 0, (hipStream_t)stream, a);
+  PRL_CHECK_LAUNCH("k_lm_gemm (forward)");
+  return PRL_OK;
+}
+
+extern "C" int prl_sum_parts(const void* parts, int parts_dtype, int64_t part_stride, int32_t nparts, int64_t n,
+                             void* out, void* stream);
+
+extern "C" int prl_lm_head_bwd_input(const void* dlogits, int64_t dlogits_stride, const void* weight,
+                                     int64_t weight_stride, void* dhidden, int64_t dhidden_stride, int64_t T, int64_t H,
+                                     int64_t V, void* workspace, size_t workspace_bytes, void* stream) {
+  clear_error();
+  PRL_REQUIRE(dlogits && weight && dhidden, "prl_lm_head_bwd_input: null pointer");
+  PRL_REQUIRE(prl_lm_head_supported(PRL_BF16, T, H, V), "prl_lm_head_bwd_input: unsupported shape T=%lld H=%lld V=%lld",
+              (long long)T, (long long)H, (long long)V);
+  PRL_REQUIRE(aligned16(dlogits) && aligned16(weight) && aligned16(dhidden) && dlogits_stride % 8 == 0 &&
+                  weight_stride % 8 == 0 && dhidden_stride % 4 == 0 && dlogits_stride >= V && weight_stride >= H &&
+                  dhidden_stride >= H,
+              "prl_lm_head_bwd_input: pointers must be 16-byte aligned and row strides multiples of 8 elements");
+  const int s = dx_splits(T, H, V);
+  if (s == 1) {
+    const GemmArgs a = make_args(dlogits, dlogits_stride, weight, weight_stride, dhidden, dhidden_stride, T, H, V, 1);
+    hipLaunchKernelGGL((k_lm_gemm<false, kOutBf16>), dim3(gemm_grid(a)), dim3(kGemmThreads), 0, (hipStream_t)stream,
+                       a);
+    PRL_CHECK_LAUNCH("k_lm_gemm (input gradient)");
+    return PRL_OK;
+  }
+  PRL_REQUIRE(dhidden_stride == H, "prl_lm_head_bwd_input: a K-split product needs a contiguous dhidden");
+  const size_t need = (size_t)s * (size_t)T * (size_t)H * sizeof(float);
+  PRL_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= need,
+              "prl_lm_head_bwd_input: workspace of %zu bytes needed (prl_lm_head_workspace_bytes), got %zu", need,
+              workspace_bytes);
+  const GemmArgs a = make_args(dlogits, dlogits_stride, weight, weight_stride, workspace, H, T, H, V, s);
+  hipLaunchKernelGGL((k_lm_gemm<false, kOutF32Slab>), dim3(gemm_grid(a)), dim3(kGemmThreads), 0, (hipStream_t)stream,
+                     a);
+  PRL_CHECK_LAUNCH("k_lm_gemm (input gradient, K split)");
+  return prl_sum_parts(workspace, PRL_F32, T * H, a.nsplit, T * H, dhidden, stream);
+}
+
+extern "C" int prl_lm_head_bwd_weight(const void* dlogits, int64_t dlogits_stride, const void* hidden,
+                                      int64_t hidden_stride, void* dweight, int64_t dweight_stride, int64_t T,
+                                      int64_t H, int64_t V, void* workspace, size_t workspace_bytes, void* stream) {
+  clear_error();
+  PRL_REQUIRE(dlogits && hidden && dweight, "prl_lm_head_bwd_weight: null pointer");
+  PRL_REQUIRE(prl_lm_head_supported(PRL_BF16, T, H, V),
+              "prl_lm_head_bwd_weight: unsupported shape T=%lld H=%lld V=%lld", (long long)T, (long long)H,
+              (long long)V);
+  PRL_REQUIRE(aligned16(dlogits) && aligned16(hidden) && aligned16(dweight) && dlogits_stride % 8 == 0 &&
+                  hidden_stride % 8 == 0 && dweight_stride % 4 == 0 && dlogits_stride >= V && hidden_stride >= H &&
+                  dweight_stride >= H,
+              "prl_lm_head_bwd_weight: pointers must be 16-byte aligned and row strides multiples of 8 elements");
+  const size_t need = (size_t)T * (size_t)H * sizeof(uint16_t);
+  PRL_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= need,
+              "prl_lm_head_bwd_weight: workspace of %zu bytes needed (prl_lm_head_workspace_bytes), got %zu", need,
+              workspace_bytes);
+  // hidden^T [H][T] into the workspace, then dweight^T = hidden^T . dlogits stored transposed
+  hipLaunchKernelGGL(k_transpose_bf16, dim3((unsigned)((H + 63) / 64), (unsigned)((T + 63) / 64)), dim3(256), 0,
+                     (hipStream_t)stream, reinterpret_cast<const uint16_t*>(hidden), hidden_stride,
+                     reinterpret_cast<uint16_t*>(workspace), T, (int)T, (int)H);
+  PRL_CHECK_LAUNCH("k_transpose_bf16");
+  const GemmArgs a = make_args(workspace, T, dlogits, dlogits_stride, dweight, dweight_stride, H, V, T, 1);
+  hipLaunchKernelGGL((k_lm_gemm<false, kOutBf16Transposed>), dim3(gemm_grid(a)), dim3(kGemmThreads), 0,
+                     (hipStream_t)stream, a);
+  PRL_CHECK_LAUNCH("k_lm_gemm (weight gradient)");
+  return PRL_OK;
+}

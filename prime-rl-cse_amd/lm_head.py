@@ -1,0 +1,114 @@
+"""The LM head's three matrix products on this package's MFMA kernels (csrc/lm_head.hip).
+
+The reference ends its forward with the model's final projection (src/prime_rl/trainer/model.py:251-254) and lets
+autograd form the two products of its backward behind `loss.backward()` (src/prime_rl/trainer/rl/train.py:310),
+all three through the BLAS library.  `lm_head(hidden, weight)` is `torch.nn.functional.linear(hidden, weight)` for
+bf16 matrices with those three products run by `prl_lm_head_fwd`, `prl_lm_head_bwd_input` and
+`prl_lm_head_bwd_weight`.  There is no fallback inside these functions: a shape the kernels do not take raises, and
+callers that want the library product for such shapes ask `supported()` first.
+"""
+
+from __future__ import annotations
+
+from ctypes import c_int64, c_size_t
+
+import torch
+
+from . import _capi
+from ._capi import check, on_device, ptr, require_device, stream_ptr, timed
+
+
+def supported(hidden: torch.Tensor, weight: torch.Tensor) -> bool:
+    """Whether `lm_head(hidden, weight)` takes these matrices: bf16 on a HIP device, [.., H] and [V, H] with unit
+    stride along H, and T, H, V multiples of 64."""
+    if hidden.dtype != torch.bfloat16 or weight.dtype != torch.bfloat16 or not hidden.is_cuda or not weight.is_cuda:
+        return False
+    if weight.dim() != 2 or hidden.dim() < 2 or hidden.shape[-1] != weight.shape[1]:
+        return False
+    t = hidden.numel() // hidden.shape[-1]
+    v, h = weight.shape
+    return bool(_capi.load().prl_lm_head_supported(_capi.PRL_BF16, t, h, v))
+
+
+def _rows(x: torch.Tensor, what: str) -> torch.Tensor:
+    """x as a 2-D matrix whose rows are 16-byte aligned with unit stride inside a row (a copy if it is not)."""
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.stride(1) != 1 or x2.stride(0) % 8 != 0 or x2.data_ptr() % 16 != 0:
+        x2 = x2.contiguous()
+    if x2.dtype != torch.bfloat16:
+        raise RuntimeError(f"{what} must be bfloat16, got {x2.dtype}")
+    return x2
+
+
+def _workspace(t: int, h: int, v: int, device: torch.device) -> tuple[torch.Tensor, int]:
+    n = int(_capi.load().prl_lm_head_workspace_bytes(t, h, v))
+    return torch.empty(max(n, 16), dtype=torch.uint8, device=device), n
+
+
+def lm_head_fwd(hidden: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """logits[T, V] = hidden[T, H] . weight[V, H]^T (no autograd)."""
+    dev = require_device(hidden, weight)
+    x, w = _rows(hidden, "hidden"), _rows(weight, "weight")
+    t, h = x.shape
+    v = w.shape[0]
+    out = torch.empty((t, v), dtype=torch.bfloat16, device=dev)
+    with on_device(dev), timed("prl_lm_head_fwd", dev):
+        check(_capi.load().prl_lm_head_fwd(ptr(x), c_int64(x.stride(0)), ptr(w), c_int64(w.stride(0)), ptr(out),
+                                           c_int64(v), c_int64(t), c_int64(h), c_int64(v), stream_ptr(dev)),
+              "prl_lm_head_fwd")
+    return out
+
+
+def lm_head_bwd_input(dlogits: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """dhidden[T, H] = dlogits[T, V] . weight[V, H]."""
+    dev = require_device(dlogits, weight)
+    g, w = _rows(dlogits, "dlogits"), _rows(weight, "weight")
+    t, v = g.shape
+    h = w.shape[1]
+    out = torch.empty((t, h), dtype=torch.bfloat16, device=dev)
+    ws, n = _workspace(t, h, v, dev)
+    with on_device(dev), timed("prl_lm_head_bwd_input", dev):
+        check(_capi.load().prl_lm_head_bwd_input(ptr(g), c_int64(g.stride(0)), ptr(w), c_int64(w.stride(0)), ptr(out),
+                                                 c_int64(h), c_int64(t), c_int64(h), c_int64(v), ptr(ws), c_size_t(n),
+                                                 stream_ptr(dev)),
+              "prl_lm_head_bwd_input")
+    return out
+
+
+def lm_head_bwd_weight(dlogits: torch.Tensor, hidden: torch.Tensor) -> torch.Tensor:
+    """dweight[V, H] = dlogits[T, V]^T . hidden[T, H]."""
+    dev = require_device(dlogits, hidden)
+    g, x = _rows(dlogits, "dlogits"), _rows(hidden, "hidden")
+    t, v = g.shape
+    h = x.shape[1]
+    out = torch.empty((v, h), dtype=torch.bfloat16, device=dev)
+    ws, n = _workspace(t, h, v, dev)
+    with on_device(dev), timed("prl_lm_head_bwd_weight", dev):
+        check(_capi.load().prl_lm_head_bwd_weight(ptr(g), c_int64(g.stride(0)), ptr(x), c_int64(x.stride(0)), ptr(out),
+                                                  c_int64(h), c_int64(t), c_int64(h), c_int64(v), ptr(ws), c_size_t(n),
+                                                  stream_ptr(dev)),
+              "prl_lm_head_bwd_weight")
+    return out
+
+
+class _LMHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hidden: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+        ctx.save_for_backward(hidden, weight)
+        out = lm_head_fwd(hidden, weight)
+        return out.view(*hidden.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, grad: torch.Tensor):
+        hidden, weight = ctx.saved_tensors
+        gh = gw = None
+        if ctx.needs_input_grad[0]:
+            gh = lm_head_bwd_input(grad, weight).view(hidden.shape)
+        if ctx.needs_input_grad[1]:
+            gw = lm_head_bwd_weight(grad, hidden)
+        return gh, gw
+
+
+def lm_head(hidden: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """`torch.nn.functional.linear(hidden, weight)` (no bias) with all three products on the MFMA kernels."""
+    return _LMHead.apply(hidden, weight)
