@@ -15,8 +15,8 @@
 // one of two LDS stages by direct-to-LDS loads (no registers on the way); the LDS images are XOR-swizzled through the
 // per-lane SOURCE address so that the 16-byte row reads and the transposing reads are free of bank conflicts.  A
 // K-tile is four phases (one 64 x 32 quadrant of the wave's output each, 16 MFMAs); a phase is a load section (LDS
-// reads for this phase, direct-to-LDS loads for the next K-tile) and an MFMA section, separated by barriers, and the
-// two waves that share a SIMD run one section apart, so that one computes while the other loads.
+// reads for this phase, two direct-to-LDS pieces for the K-tiles ahead) and an MFMA section, separated by barriers,
+// and the two waves that share a SIMD run one section apart, so that one computes while the other loads.
 #include "prl_common.h"
 
 namespace prl {
@@ -154,19 +154,14 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
   // LDS destination of piece j of this wave inside a stage (the hardware adds 16 * lane)
   char* const wave_dst = smem + wid * 1024;
 
-  auto stage_p = [&](int stage) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      glds16(psrc[j], wave_dst + stage * kStageBytes + j * 8192);
-      psrc[j] += pstep;
-    }
+  // piece j of P / of Q for this thread's next K-tile of that piece, into `stage`
+  auto issue_p = [&](int stage, int j) {
+    glds16(psrc[j], wave_dst + stage * kStageBytes + j * 8192);
+    psrc[j] += pstep;
   };
-  auto stage_q = [&](int stage) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      glds16(qsrc[j], wave_dst + stage * kStageBytes + 2 * kQuarterBytes + j * 8192);
-      qsrc[j] += qstep;
-    }
+  auto issue_q = [&](int stage, int j) {
+    glds16(qsrc[j], wave_dst + stage * kStageBytes + 2 * kQuarterBytes + j * 8192);
+    qsrc[j] += qstep;
   };
 
   // ---- fragment addresses (bytes inside a stage)
@@ -267,54 +262,76 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  // ---- prologue: K-tile 0 into stage 0
-  stage_p(0);
-  stage_q(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // ---- prologue: K-tile 0 into stage 0, and the first two pieces of Q of K-tile 1
+#pragma unroll
+  for (int j = 0; j < 4; ++j) issue_p(0, j);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) issue_q(0, j);
+  if (nk > 1) {
+    issue_q(1, 0);
+    issue_q(1, 1);
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   bar();
-  load_b(0, 0, bx);
-  wait_tr_reads(bx);
   if (wid >= 4) bar();  // waves 4-7 run one section behind waves 0-3
 
-  // One K-tile.  EVEN tiles multiply in the order (a0, bx) (a0, by) (a1, by) (a1, bx) and leave with the next
-  // tile's by loaded; odd tiles (a0, by) (a0, bx) (a1, bx) (a1, by) and leave with the next tile's bx loaded.
-  // The next K-tile's direct-to-LDS loads are issued in the first two load sections and waited for at the end of
-  // the third; the barrier behind that wait orders them for every wave's reads from the fourth section on.  The
-  // stage they overwrite was last read two K-tile phases earlier.  The fourth section's reads (asm, not counted by
-  // the compiler) are waited for behind that phase's MFMAs, so their registers are final before the loop's
-  // back-edge, where the compiler may copy them.
-#define PRL_GEMM_TILE(EVEN)                                                         \
+  // One K-tile u out of stage S: four phases, each a load section, a barrier, an MFMA section, a barrier.
+  //   phase 0: reads a0 (rows 0-63 of the wave) and b0 (columns 0-31);   multiplies (a0, b0)
+  //   phase 1: reads b1;                                                 multiplies (a0, b1)
+  //   phase 2: reads a1;                                                 multiplies (a1, b1)
+  //   phase 3: reads nothing;                                            multiplies (a1, b0)
+  // Every load section also issues two of the eight direct-to-LDS pieces a thread contributes per K-tile, as early
+  // as the slot they overwrite is dead: Q of tile u+2 goes into THIS stage from phase 3 on (its Q slots were last
+  // read in phase 1), the rest of Q and then P of tile u+1 into the other stage in phases 0-2.  A slot counts as
+  // dead once every wave has waited for its last reads of it and a barrier has followed.  Pieces are waited for
+  // with counted waits (a wave's vector-memory operations retire in issue order), always before a barrier that
+  // every reader passes before its first read:
+  //   end of phase 3's load section: Q of u+1 and the a0 pieces of P of u+1 (read from phase 0 of u+1 on); what may
+  //     stay in flight: the a1 pieces of u+1 and the two pieces of Q of u+2 just issued;
+  //   end of phase 1's load section: the a1 pieces of P of u (read in phase 2); in flight: all six younger pieces.
+#define PRL_GEMM_TILE(S)                                                            \
   {                                                                                 \
-    const int st = (EVEN) ? 0 : 1;                                                  \
-    const bool has_next = t + 1 < nk;                                               \
-    if (has_next) stage_p(st ^ 1);                                                  \
-    load_a(st, 0);                                                                  \
+    const bool n1 = u + 1 < nk, n2 = u + 2 < nk;                                    \
+    if (n1) { issue_q((S) ^ 1, 2); issue_q((S) ^ 1, 3); }                           \
+    load_a((S), 0);                                                                 \
+    load_b((S), 0, bx);                                                             \
     bar();                                                                          \
-    if (EVEN) mma(0, 0, bx); else mma(0, 1, by);                                    \
+    wait_tr_reads(bx);                                                              \
+    mma(0, 0, bx);                                                                  \
     bar();                                                                          \
-    if (has_next) stage_q(st ^ 1);                                                  \
-    if (EVEN) load_b(st, 1, by); else load_b(st, 0, bx);                            \
+    if (n1) { issue_p((S) ^ 1, 0); issue_p((S) ^ 1, 2); }                           \
+    load_b((S), 1, by);                                                             \
+    if (n1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                        \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           \
     bar();                                                                          \
-    if (EVEN) { wait_tr_reads(by); mma(0, 1, by); } else { wait_tr_reads(bx); mma(0, 0, bx); } \
+    wait_tr_reads(by);                                                              \
+    mma(0, 1, by);                                                                  \
     bar();                                                                          \
-    load_a(st, 1);                                                                  \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                \
+    if (n1) { issue_p((S) ^ 1, 1); issue_p((S) ^ 1, 3); }                           \
+    load_a((S), 1);                                                                 \
     bar();                                                                          \
-    if (EVEN) mma(1, 1, by); else mma(1, 0, bx);                                    \
+    mma(1, 1, by);                                                                  \
     bar();                                                                          \
-    if (has_next) { if (EVEN) load_b(st ^ 1, 1, by); else load_b(st ^ 1, 0, bx); }  \
+    if (n2) {                                                                       \
+      issue_q((S), 0);                                                              \
+      issue_q((S), 1);                                                              \
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                              \
+    } else if (n1) {                                                                \
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                              \
+    }                                                                               \
     bar();                                                                          \
-    if (EVEN) mma(1, 0, bx); else mma(1, 1, by);                                    \
-    if (has_next) { if (EVEN) wait_tr_reads(by); else wait_tr_reads(bx); }          \
+    mma(1, 0, bx);                                                                  \
     bar();                                                                          \
   }
 
-  for (int t = 0; t < nk; t += 2) {
-    PRL_GEMM_TILE(true)
-    ++t;
-    if (t >= nk) break;
-    PRL_GEMM_TILE(false)
-    --t;
+  for (int u = 0; u < nk; u += 2) {
+    PRL_GEMM_TILE(0)
+    ++u;
+    if (u >= nk) break;
+    PRL_GEMM_TILE(1)
+    --u;
   }
 #undef PRL_GEMM_TILE
   if (wid < 4) bar();
