@@ -17,6 +17,8 @@
 // K-tile is four phases (one 64 x 32 quadrant of the wave's output each, 16 MFMAs); a phase is a load section (LDS
 // reads for this phase, two direct-to-LDS pieces for the K-tiles ahead) and an MFMA section, separated by barriers,
 // and the two waves that share a SIMD run one section apart, so that one computes while the other loads.
+#include <stdlib.h>
+
 #include "prl_common.h"
 
 namespace prl {
@@ -47,6 +49,7 @@ struct GemmArgs {
   int nsplit;
   int mtiles, ntiles;  // ceil(M / 256), ceil(N / 256)
   int super_m, super_n;  // ceil(mtiles / 8), ceil(ntiles / 4)
+  int stagger_ticks;     // 0, or one tile's duration in ticks of the 100 MHz clock (see k_lm_gemm)
 };
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
@@ -115,6 +118,17 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 2, wc = wid & 3;
   const int m0 = mt * kBM, n0 = nt * kBN;
+
+  // Every compute unit gets the same work, so left alone they all reach their tile's write-back at the same
+  // moment, round after round, and the chip alternates between computing with idle memory and writing 32 MB at
+  // the memory's rate with idle matrix units.  The first workgroup of each compute unit therefore starts late by
+  // its own fraction of a tile's duration (bounded: at most stagger_ticks of the 100 MHz clock), which spreads
+  // the write-backs over the tile period for the rest of the launch; later workgroups inherit the offset.
+  if (a.stagger_ticks > 0 && blockIdx.x < 256u) {
+    const unsigned frac = ((unsigned)blockIdx.x * 157u) & 255u;  // a different 1/256th for each of the first 256
+    const unsigned long long until = wall_clock64() + (unsigned long long)((unsigned)a.stagger_ticks * frac >> 8);
+    while (wall_clock64() < until) __builtin_amdgcn_s_sleep(32);
+  }
 
   // ---- staging: per thread four 16-byte pieces of P and four of Q per K-tile
   // P (and a K-major Q): the quarter is [128 rows][64 k] with 128-byte rows; LDS slot (16 bytes) s = row * 8 + chunk
@@ -338,6 +352,9 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
 
   // ---- epilogue: every lane holds, per accumulator tile, 4 consecutive elements along the contiguous index
   const int lr = lane & 15, lq = lane >> 4;
+#ifdef PRL_GEMM_SKIP_STORE  // timing experiment only: the tile is computed and (almost surely) not stored
+  if (acc[0][0][0] != 12345.678f) return;
+#endif
   if (OUT == kOutBf16Transposed) {
     uint16_t* C = reinterpret_cast<uint16_t*>(a.C);
 #pragma unroll
@@ -353,24 +370,54 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
         }
       }
     }
-  } else {
+  } else if (OUT == kOutF32Slab) {
+    float* C = reinterpret_cast<float*>(a.C) + (int64_t)split * a.slab_stride;
 #pragma unroll
     for (int rt = 0; rt < 8; ++rt) {
       const int m = m0 + wr * 128 + 16 * rt + lr;
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) {
         const int n = n0 + wc * 64 + 16 * ct + 4 * lq;
-        if (m < a.M && n < a.N) {
-          const f32x4 v = acc[rt][ct];
-          if (OUT == kOutF32Slab) {
-            float* C = reinterpret_cast<float*>(a.C) + (int64_t)split * a.slab_stride;
-            *reinterpret_cast<f32x4*>(C + (int64_t)m * a.ldc + n) = v;
-          } else {
-            uint16_t* C = reinterpret_cast<uint16_t*>(a.C);
-            u32x2_t o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
-            *reinterpret_cast<u32x2_t*>(C + (int64_t)m * a.ldc + n) = o;
-          }
-        }
+        if (m < a.M && n < a.N) *reinterpret_cast<f32x4*>(C + (int64_t)m * a.ldc + n) = acc[rt][ct];
+      }
+    }
+  } else {
+    // bf16 [M][N]: the wave's 128 x 64 elements go through a 16 KB LDS image of its own (the stages are dead
+    // behind the last barrier) so that every store instruction writes 8 whole 128-byte rows, instead of 16
+    // pieces of 32 bytes: a compute unit retires stores at a few cycles per distinct line touched.  Row r of the
+    // image keeps its 16-byte slot s at s ^ (r & 7): the 8-byte writes of 16 rows and the 16-byte reads of 8 slots
+    // of two rows then spread over the banks.
+    char* img = smem + wid * 16384;
+#pragma unroll
+    for (int rt = 0; rt < 8; ++rt) {
+      const int r = 16 * rt + lr;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const f32x4 v = acc[rt][ct];
+        const u32x2_t o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+        *reinterpret_cast<u32x2_t*>(img + r * 128 + (((2 * ct + (lq >> 1)) ^ (r & 7)) * 16) + 8 * (lq & 1)) = o;
+      }
+    }
+    uint16_t* C = reinterpret_cast<uint16_t*>(a.C);
+    const int n = n0 + wc * 64 + 8 * (lane & 7);
+    const int mw = m0 + wr * 128 + (lane >> 3);
+    const char* src = img + (lane >> 3) * 128;
+    const int slot = lane & 7, rsw = (lane >> 3) & 7;  // row r = 8 it + (lane >> 3): r & 7 does not depend on it
+    uint16_t* dst = C + (int64_t)mw * a.ldc + n;
+    if (m0 + kBM <= a.M && n0 + kBN <= a.N) {
+      // tile inside the matrix: all reads first, then all stores, nothing conditional
+      u32x4 v[16];
+#pragma unroll
+      for (int it = 0; it < 16; ++it) v[it] = *reinterpret_cast<const u32x4*>(src + it * 1024 + ((slot ^ rsw) * 16));
+#pragma unroll
+      for (int it = 0; it < 16; ++it)
+        __builtin_nontemporal_store(v[it], reinterpret_cast<u32x4*>(dst + (int64_t)(8 * it) * a.ldc));
+    } else {
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(src + it * 1024 + ((slot ^ rsw) * 16));
+        if (mw + 8 * it < a.M && n < a.N)
+          __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst + (int64_t)(8 * it) * a.ldc));
       }
     }
   }
@@ -405,6 +452,12 @@ __global__ void __launch_bounds__(256) k_transpose_bf16(const uint16_t* __restri
   }
 }
 
+static int forward_stagger(int ktiles) {
+  const char* e = getenv("PRL_LM_HEAD_STAGGER");  // ticks of 10 ns per K-tile; 0 switches the spreading off
+  const int per_tile = e ? atoi(e) : 150;
+  return per_tile <= 0 ? 0 : per_tile * ktiles;
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 static GemmArgs make_args(const void* P, int64_t ldp, const void* Q, int64_t ldq, void* C, int64_t ldc, int64_t M,
@@ -426,6 +479,7 @@ static GemmArgs make_args(const void* P, int64_t ldp, const void* Q, int64_t ldq
   a.ntiles = (int)((N + kBN - 1) / kBN);
   a.super_m = (a.mtiles + kSuperM - 1) / kSuperM;
   a.super_n = (a.ntiles + kSuperN - 1) / kSuperN;
+  a.stagger_ticks = 0;
   return a;
 }
 static unsigned gemm_grid(const GemmArgs& a) {
@@ -470,9 +524,11 @@ extern "C" int prl_lm_head_fwd(const void* hidden, int64_t hidden_stride, const 
               (long long)T, (long long)H, (long long)V);
   PRL_REQUIRE(aligned16(hidden) && aligned16(weight) && aligned16(logits) && hidden_stride % 8 == 0 &&
                   weight_stride % 8 == 0 && logits_stride % 4 == 0 && hidden_stride >= H && weight_stride >= H &&
-                  logits_stride >= V,
+                  logits_stride >= V && logits_stride % 8 == 0,
               "prl_lm_head_fwd: pointers must be 16-byte aligned and row strides multiples of 8 elements");
-  const GemmArgs a = make_args(hidden, hidden_stride, weight, weight_stride, logits, logits_stride, T, V, H, 1);
+  GemmArgs a = make_args(hidden, hidden_stride, weight, weight_stride, logits, logits_stride, T, V, H, 1);
+  // write-backs are a sixth of this product's time at H = 1024: spread them (k_lm_gemm); a K-tile takes ~1.5 us
+  if ((int64_t)a.mtiles * a.ntiles >= 1024) a.stagger_ticks = forward_stagger(a.ktiles);
   hipLaunchKernelGGL((k_lm_gemm<true, kOutBf16>), dim3(gemm_grid(a)), dim3(kGemmThreads), 0, (hipStream_t)stream, a);
   PRL_CHECK_LAUNCH("k_lm_gemm (forward)");
   return PRL_OK;
@@ -489,7 +545,7 @@ extern "C" int prl_lm_head_bwd_input(const void* dlogits, int64_t dlogits_stride
   PRL_REQUIRE(prl_lm_head_supported(PRL_BF16, T, H, V), "prl_lm_head_bwd_input: unsupported shape T=%lld H=%lld V=%lld",
               (long long)T, (long long)H, (long long)V);
   PRL_REQUIRE(aligned16(dlogits) && aligned16(weight) && aligned16(dhidden) && dlogits_stride % 8 == 0 &&
-                  weight_stride % 8 == 0 && dhidden_stride % 4 == 0 && dlogits_stride >= V && weight_stride >= H &&
+                  weight_stride % 8 == 0 && dhidden_stride % 8 == 0 && dlogits_stride >= V && weight_stride >= H &&
                   dhidden_stride >= H,
               "prl_lm_head_bwd_input: pointers must be 16-byte aligned and row strides multiples of 8 elements");
   const int s = dx_splits(T, H, V);
