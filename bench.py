@@ -42,6 +42,7 @@ SEQ_LEN = 128
 MICRO_BATCH = 16
 BATCH = 128
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 matrix peak
 EXIT_TRAINER_EXTRA_HUNG = 3  # exit code when the whole-trainer-step extra (or the barrier behind it) never returned
 
 
@@ -91,11 +92,15 @@ def parse(argv: list[str] | None = None) -> argparse.Namespace:
     p.add_argument("--launch-check", action="store_true",
                    help="ranks only meet, all-reduce one number and rank 0 prints what it saw: a test of the launch "
                         "path that needs no GPU (with PRL_BENCH_BACKEND=gloo)")
-    p.add_argument("--trainer-impl", choices=["hf", "fused", "replica", "graphed"], default="replica",
+    p.add_argument("--trainer-impl", choices=["hf", "fused", "replica"], default="replica",
                    help="whole-trainer-step workload: hf = the transformers blocks as they are under FSDP2; fused = "
                         "their RMSNorm / rotary / SwiGLU on this package's HIP kernels (the reference's model.impl = "
-                        "liger_kernel); replica = fused, the whole model on every GPU with sharded master weights; "
-                        "graphed = replica with every micro-batch replayed from a HIP graph")
+                        "liger_kernel); replica = fused, the whole model on every GPU with sharded master weights. "
+                        "(Replaying the passes from HIP graphs is not offered: library calls record memset nodes "
+                        "into a captured pass, and such nodes have given wrong results on replay.)")
+    p.add_argument("--no-paths", action="store_true",
+                   help="leave out the short measurements of the other product paths (fp32 logits, two passes, one "
+                        "ratio per sample, the reference's fake-data distribution) and of the LM head's products")
     return p.parse_args(argv)
 
 
@@ -154,6 +159,138 @@ def run_step(rows, cfg, with_stats: bool):
     # asynchronously and are read one step later, as a trainer that logs step N during step N + 1 would
     stats = tensors.compute_stats_async() if with_stats else None
     return out, stats
+
+
+def measure_path(rows, cfg, with_stats: bool, steps: int, dominant: str, bytes_per_launch: float, env: dict | None = None
+                 ) -> dict:
+    """A short measurement of one product path over the same 8 packed rows: `steps` timed steps after one warm-up
+    step, then one more step with an event on either side of every library call for the kernel times.  `env`
+    holds switches of the package set for the duration (they are read at every call)."""
+    from prime_rl_cse_amd import _capi
+
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        _, fut = run_step(rows, cfg, with_stats)
+        if fut is not None:
+            fut.result()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            _, fut = run_step(rows, cfg, with_stats)
+            if fut is not None:
+                fut.result()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        side = _capi.KernelTimer()
+        _capi.set_timer(side)
+        _, fut = run_step(rows, cfg, with_stats)
+        if fut is not None:
+            fut.result()
+        torch.cuda.synchronize()
+        _capi.set_timer(None)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    k = side.summary()
+    out = {"ms_per_step": ms, "samples_per_s": BATCH / (ms * 1e-3), "steps": steps,
+           "calls": {name: round(v["mean_ms"], 4) for name, v in sorted(k.items())}}
+    if dominant in k:
+        gbs = bytes_per_launch / (k[dominant]["mean_ms"] * 1e-3) / 1e9
+        out["dominant"] = {"call": dominant, "mean_ms": k[dominant]["mean_ms"], "GBps": gbs, "frac": gbs / HBM_PEAK_GBS,
+                           "bytes_per_launch": bytes_per_launch,
+                           "timed_by": "HIP events recorded on the launch stream on either side of the call"}
+    return out
+
+
+def lm_head_measure(dev, t: int = 16384, h: int = 1024, v: int = VOCAB, reps: int = 3, rounds: int = 3) -> dict:
+    """The LM head's three products at the shape the whole-model trainer step runs them (the step's 8 rows joined:
+    16384 x 1024 against the 151936 x 1024 table): this package's MFMA kernels and the BLAS library's product
+    through torch, interleaved in random order, HIP events around `reps` back-to-back calls, medians over the
+    rounds.  Random operands (zero-filled ones run at a higher clock)."""
+    import random
+
+    from prime_rl_cse_amd import lm_head as L
+
+    gen = torch.Generator(device=dev).manual_seed(0)
+    x = torch.randn((t, h), generator=gen, device=dev).to(torch.bfloat16)
+    w = (torch.randn((v, h), generator=gen, device=dev) * 0.05).to(torch.bfloat16)
+    g = torch.empty((t, v), dtype=torch.bfloat16, device=dev)
+    for r in range(0, t, 2048):
+        g[r:r + 2048] = (torch.randn((min(2048, t - r), v), generator=gen, device=dev) * 0.01).to(torch.bfloat16)
+    ours = {"forward": lambda: L.lm_head_fwd(x, w), "input_gradient": lambda: L.lm_head_bwd_input(g, w),
+            "weight_gradient": lambda: L.lm_head_bwd_weight(g, x)}
+    lib = {"forward": lambda: torch.nn.functional.linear(x, w), "input_gradient": lambda: g @ w,
+           "weight_gradient": lambda: g.t() @ x}
+
+    def ms(fn) -> float:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        b.synchronize()
+        return a.elapsed_time(b) / reps
+
+    for k in ours:
+        ours[k]()
+        lib[k]()
+    torch.cuda.synchronize()
+    times = {(k, who): [] for k in ours for who in ("kernel", "library")}
+    rnd = random.Random(0)
+    for _ in range(rounds):
+        order = list(times)
+        rnd.shuffle(order)
+        for k, who in order:
+            times[(k, who)].append(ms(ours[k] if who == "kernel" else lib[k]))
+    flop = 2.0 * t * h * v
+    products = {}
+    for k in ours:
+        a, b = sorted(times[(k, "kernel")]), sorted(times[(k, "library")])
+        ma, mb = a[len(a) // 2], b[len(b) // 2]
+        products[k] = {"mean_ms": ma, "tflops": flop / ma / 1e9, "frac": flop / ma / 1e9 / MFMA_PEAK_TFLOPS,
+                       "library_ms": mb, "library_tflops": flop / mb / 1e9, "kernel_over_library": mb / ma}
+    plan = L.plan(t, h, v)
+    best = max(products, key=lambda k: products[k]["frac"])
+    return {"bound": "mfma", "kernel": "k_lm_gemm", "unit": "TFLOP/s", "peak": MFMA_PEAK_TFLOPS,
+            "flops": flop, "achieved": products[best]["tflops"], "frac": products[best]["frac"],
+            "mean_ms": products[best]["mean_ms"], "product": best, "products": products,
+            "shape": {"T": t, "H": h, "V": v},
+            "in_the_trainer_by_default": {"forward": plan[0], "input_gradient": plan[1], "weight_gradient": plan[2]},
+            "timed_by": f"HIP events around {reps} back-to-back calls, kernel and library interleaved in random "
+                        f"order, median of {rounds} rounds, random bf16 operands"}
+
+
+def other_paths(dev, rows, cfg, with_stats, args, ms_per_step, dom, achieved, dom_bytes) -> dict:
+    """The product paths the headline does not take, a few steps each over the same shape (8 packed rows of
+    T = 2048, V = 151936): two passes over bf16 logits (what the one-pass kernel replaces; also what logits it does
+    not take fall back to), one ratio per sample (src/prime_rl/trainer/rl/loss.py:92-96, 107-108), fp32 logits
+    (the reference's own storage type, loss.py:26-30 after train.py:285)."""
+    import prime_rl_cse_amd as prl
+
+    t = MICRO_BATCH * SEQ_LEN
+    paths = {"token_bf16": {"ms_per_step": ms_per_step, "samples_per_s": BATCH / (ms_per_step * 1e-3),
+                            "dominant": {"call": "prl_policy_rows_fwd_bwd", "mean_ms": dom["mean_ms"], "GBps": achieved,
+                                         "frac": achieved / HBM_PEAK_GBS, "bytes_per_launch": dom_bytes},
+                            "note": "the headline"}}
+    bwd2 = (t - 1) * VOCAB * 2 + t * VOCAB * 2
+    paths["token_bf16_two_pass"] = measure_path(rows, cfg, with_stats, 3, "prl_logprob_bwd", bwd2,
+                                                env={"PRL_FUSED_ROWS": "0"})
+    seq_cfg = prl.LossConfig(ratio_type="sequence")
+    paths["sequence_bf16"] = measure_path(rows, seq_cfg, with_stats, 3, "prl_policy_rows_seq_fwd_bwd", bwd2 + 12 * t)
+    # fp32 logits: the same values widened (8 rows of 1.24 GB); the bf16 rows are not needed meanwhile
+    wide = []
+    for r in rows:
+        w = dict(r)
+        w["logits"] = r["logits"].detach().float()
+        wide.append(w)
+    paths["token_f32"] = measure_path(wide, cfg, with_stats, 3, "prl_logprob_bwd", (t - 1) * VOCAB * 4 + t * VOCAB * 4)
+    del wide
+    torch.cuda.empty_cache()
+    return paths
 
 
 def cpu_baseline(rows, seconds: float) -> dict:
@@ -222,13 +359,12 @@ def trainer_measure(dev, world: int, steps: int, warmup: int, cpu: bool, cpu_sec
         fused_modules = fused.fuse_model(model)
     fsdp_groups = T.blocks_per_fsdp_group(model)
     replica = None
-    if impl in ("graphed", "replica"):  # whole model per GPU, micro-batches from HIP graphs ("replica": eagerly)
+    if impl == "replica":  # whole model per GPU
         from prime_rl_cse_amd.replica import Replica
 
         from prime_rl_cse_amd.optim import FlatAdamW
 
-        replica = Replica(model, lambda m: FlatAdamW(m.parameters(), lr=1e-6, weight_decay=0.01),
-                          graphs=impl == "graphed")
+        replica = Replica(model, lambda m: FlatAdamW(m.parameters(), lr=1e-6, weight_decay=0.01), graphs=False)
         opt = replica.optimizer
 
         def step(mbs):
@@ -687,8 +823,27 @@ def main(argv: list[str] | None = None) -> int:
                                        if k in last_stats}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(rows, args.cpu_seconds)
+        if world == 1 and not args.no_paths and dtype == torch.bfloat16:
+            line["paths"] = other_paths(dev, rows, cfg, with_stats, args, ms_per_step, dom, achieved, dom_bytes)
+            if args.data != "fake":
+                del rows
+                torch.cuda.empty_cache()
+                fake = make_batch(dev, dtype, "fake", 1234 + rank)
+                m = measure_path(fake, cfg, with_stats, 3, "prl_policy_rows_fwd_bwd", dom_bytes)
+                line["value_fake_data"] = m["samples_per_s"]
+                line["paths"]["token_bf16_fake_data"] = {
+                    **m, "inputs": "the reference's FakeDataLoader distribution (src/prime_rl/trainer/rl/data.py:39-54): "
+                                   "sampler log-probabilities ~ N(0, 1), so most ratios hit the clip and their rows "
+                                   "get a zero gradient without being read"}
+                rows = fake
     del rows
     torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.no_paths:
+        try:
+            line["roofline_lm_head"] = lm_head_measure(dev)
+        except Exception as exc:
+            line["roofline_lm_head"] = {"error": f"{type(exc).__name__}: {exc}"}
+        torch.cuda.empty_cache()
 
     # The whole-trainer-step extra runs on every rank (with more than one, the end of its step is a reduce-scatter
     # and an all-gather over RCCL).  The headline line must survive whatever happens in there: an exception is

@@ -487,16 +487,23 @@ static unsigned gemm_grid(const GemmArgs& a) {
   return 8u * 32u * (unsigned)((supers + 7) / 8);
 }
 
-// K splits for the input-gradient product: few tiles of C, a very long K.  Enough splits that the chip's 256
-// compute units all have a tile, none when the tiles alone fill it.
+// K splits for the input-gradient product: few tiles of C, a very long K.  The chip works the tiles off in rounds
+// of one per compute unit, so the time goes with ceil(tiles * splits / 256) / splits; the smallest split count
+// within 3 % of the best is taken (every split costs an fp32 slab written and read back).
 static int dx_splits(int64_t T, int64_t H, int64_t V) {
   const int64_t tiles = ((T + kBM - 1) / kBM) * ((H + kBN - 1) / kBN);
-  if (tiles >= 224) return 1;
-  int64_t s = (256 + tiles - 1) / tiles;
   const int64_t ktiles = V / kBK;
-  if (s > 16) s = 16;
-  if (s > ktiles) s = ktiles;
-  return (int)s;
+  double best = 1e30;
+  int best_s = 1;
+  for (int s = 1; s <= 16 && s * 8 <= ktiles; ++s) {
+    const double rounds = (double)((tiles * s + 255) / 256);
+    const double cost = rounds / s * (1.0 + 0.02 * (s - 1));
+    if (cost < best * 0.97) {
+      best = cost;
+      best_s = s;
+    }
+  }
+  return best_s;
 }
 
 }  // namespace prl

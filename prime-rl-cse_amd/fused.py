@@ -774,10 +774,16 @@ def _v_forward(self: nn.Module, x: Tensor) -> Tensor:
     return self._prl_torch_forward(x)
 
 
+def _lm_head_forward(self: nn.Module, hidden_states: Tensor) -> Tensor:
+    from . import lm_head as LM
+
+    return LM.linear(hidden_states, self.weight)
+
+
 def fuse_model(model: nn.Module) -> dict[str, int]:
     """Rebind the forward of every RMSNorm module of an HF causal LM to the HIP kernel.  Returns what was
     rebound, by kind.  Call it before FSDP wrapping or after; parameters are left as they are."""
-    done = {"rmsnorm": 0, "rope": 0, "swiglu": 0, "qkv": 0, "linear": 0, "layer": 0}
+    done = {"rmsnorm": 0, "rope": 0, "swiglu": 0, "qkv": 0, "linear": 0, "layer": 0, "lm_head": 0}
     import os
     import sys
 
@@ -791,6 +797,11 @@ def fuse_model(model: nn.Module) -> dict[str, int]:
                 _ORIGINAL_ROPE.append(home.apply_rotary_pos_emb)
             home.apply_rotary_pos_emb = apply_rotary_pos_emb  # module-wide: every model of this family in the process
         done["rope"] = 1
+    head = getattr(model, "lm_head", None)  # its products on this package's MFMA kernels where they are ahead
+    if isinstance(head, nn.Linear) and head.bias is None and not hasattr(head, "_prl_torch_forward"):
+        head._prl_torch_forward = head.forward
+        head.forward = types.MethodType(_lm_head_forward, head)
+        done["lm_head"] = 1
     for module in model.modules():
         name = type(module).__name__
         is_norm = name.endswith("RMSNorm") and hasattr(module, "weight") and hasattr(module, "variance_epsilon")

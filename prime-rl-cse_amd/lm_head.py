@@ -10,6 +10,7 @@ callers that want the library product for such shapes ask `supported()` first.
 
 from __future__ import annotations
 
+import os
 from ctypes import c_int64, c_size_t
 
 import torch
@@ -89,6 +90,68 @@ def lm_head_bwd_weight(dlogits: torch.Tensor, hidden: torch.Tensor) -> torch.Ten
                                                   stream_ptr(dev)),
               "prl_lm_head_bwd_weight")
     return out
+
+
+def plan(t: int, h: int, v: int) -> tuple[bool, bool, bool]:
+    """Which of the three products (forward, input gradient, weight gradient) of a [t, h] x [v, h] LM head run on
+    this package's kernels; the others go to the BLAS library through torch.
+
+    Default (`PRL_LM_HEAD=auto`): the two backward products, where the kernels are ahead of the library at every
+    recipe shape measured (input gradient 1.0-2.0x, weight gradient 1.10-1.28x; `tools/lm_head_shapes.sh`), and
+    the library's forward, which is 1-11 % ahead of the kernel's.  `PRL_LM_HEAD=hip` / `lib` take all three from
+    one side; `PRL_LM_HEAD_FWD`, `PRL_LM_HEAD_DX`, `PRL_LM_HEAD_DW` = 0 / 1 set one product."""
+    mode = os.environ.get("PRL_LM_HEAD", "auto")
+    if mode not in ("auto", "hip", "lib"):
+        raise RuntimeError(f"PRL_LM_HEAD must be auto, hip or lib, got {mode!r}")
+    takes = bool(_capi.load().prl_lm_head_supported(_capi.PRL_BF16, t, h, v))
+    ours = {"auto": (False, True, True), "hip": (True, True, True), "lib": (False, False, False)}[mode]
+    if not takes and mode == "auto":
+        ours = (False, False, False)
+    out = []
+    for flag, name in zip(ours, ("PRL_LM_HEAD_FWD", "PRL_LM_HEAD_DX", "PRL_LM_HEAD_DW")):
+        e = os.environ.get(name)
+        out.append(flag if e is None else e != "0")
+    if any(out) and not takes:
+        raise RuntimeError(f"the LM-head kernels do not take T={t} H={h} V={v} (multiples of 64 needed)")
+    return out[0], out[1], out[2]
+
+
+class _LMHeadMixed(torch.autograd.Function):
+    """`linear(hidden, weight)` with each of the three products on the side `plan` names."""
+
+    @staticmethod
+    def forward(ctx, hidden: torch.Tensor, weight: torch.Tensor, fwd: bool, dx: bool, dw: bool) -> torch.Tensor:
+        ctx.save_for_backward(hidden, weight)
+        ctx.ours = (dx, dw)
+        if fwd:
+            return lm_head_fwd(hidden, weight).view(*hidden.shape[:-1], weight.shape[0])
+        return torch.nn.functional.linear(hidden, weight)
+
+    @staticmethod
+    def backward(ctx, grad: torch.Tensor):
+        hidden, weight = ctx.saved_tensors
+        dx, dw = ctx.ours
+        gh = gw = None
+        g2 = grad.reshape(-1, grad.shape[-1])
+        if ctx.needs_input_grad[0]:
+            gh = (lm_head_bwd_input(g2, weight) if dx else g2 @ weight).view(hidden.shape)
+        if ctx.needs_input_grad[1]:
+            x2 = hidden.reshape(-1, hidden.shape[-1])
+            gw = lm_head_bwd_weight(g2, x2) if dw else g2.t() @ x2
+        return gh, gw, None, None, None
+
+
+def linear(hidden: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """The LM head as the trainer runs it: `torch.nn.functional.linear(hidden, weight)` with the products `plan`
+    assigns to this package's kernels taken from them.  Matrices the kernels do not take (other dtypes, sharded
+    weights, sizes that are not multiples of 64) go to torch whole."""
+    if hasattr(weight, "to_local") or not supported(hidden, weight):
+        return torch.nn.functional.linear(hidden, weight)
+    t = hidden.numel() // hidden.shape[-1]
+    fwd, dx, dw = plan(t, weight.shape[1], weight.shape[0])
+    if not (fwd or dx or dw):
+        return torch.nn.functional.linear(hidden, weight)
+    return _LMHeadMixed.apply(hidden, weight, fwd, dx, dw)
 
 
 class _LMHead(torch.autograd.Function):

@@ -325,7 +325,7 @@ def test_fuse_model_rebinds_the_gated_mlps():
     cfg = T.model_config("Qwen/Qwen3-0.6B", num_layers=3)
     model = T.get_model(cfg, DEV, torch.bfloat16, seed=3)
     done = fused.fuse_model(model)
-    assert done == {"rmsnorm": 13, "rope": 1, "swiglu": 3, "qkv": 3, "linear": 6, "layer": 3}
+    assert done == {"rmsnorm": 13, "rope": 1, "swiglu": 3, "qkv": 3, "linear": 6, "layer": 3, "lm_head": 1}
     ids = torch.randint(0, 1000, (1, 64), device=DEV)
     pos = torch.arange(64, device=DEV)[None]
     timer = prl._capi.KernelTimer()
