@@ -136,6 +136,7 @@ def run_step(rows, cfg, with_stats: bool):
     """The hot loop of src/prime_rl/trainer/rl/train.py:264-333 and :364 from the
     logits onward."""
     import prime_rl_cse_amd as prl
+    from prime_rl_cse_amd.trainer import add_ratio_statistics
 
     loss_scale = sum(int(r["loss_mask"].numel()) for r in rows)  # masks are all ones: no sync needed to count them
     tensors = prl.Tensors()
@@ -153,8 +154,7 @@ def run_step(rows, cfg, with_stats: bool):
             tensors.add("old_probs", r["logprobs"], m, exp=True)
             tensors.add("entropy", aux["entropy"], m)
             tensors.add("loss", loss.detach().reshape(1))
-            for k in ("importance_ratio", "clipped_importance_ratio", "is_clipped"):
-                tensors.add(k, aux[k], m)
+            add_ratio_statistics(tensors, aux, m, cfg)  # per token, or per sample with one ratio per sample
     # the statistics are reduced on the device inside the step; their 5 floats per key reach the host
     # asynchronously and are read one step later, as a trainer that logs step N during step N + 1 would
     stats = tensors.compute_stats_async() if with_stats else None
