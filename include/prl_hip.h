@@ -143,9 +143,10 @@ int prl_logprob_bwd_selected(const void* logits, int logits_dtype, int64_t T, in
  * index i >= 1 opens a new sample iff pos[i] == 0, pos[i-1] != 0, i+1 < T and
  * pos[i+1] == 1.
  *
- *   seg_id    int32 [T]      sample index of every token (may be NULL)
- *   seg_start int64 [T + 1]  start offsets, seg_start[n_seg] = T
- *   n_seg     int32 [1]      number of samples (1 when T > 0, 0 when T == 0)
+ *   seg_id    int32 [T]               sample index of every token (may be NULL)
+ *   seg_start int64 [max(T, 1) + 1]   start offsets, seg_start[n_seg] = T
+ *   n_seg     int32 [1]               number of samples, at least 1: an empty row (T == 0) is ONE sample of
+ *                                     length 0, as the reference's `boundaries = [0]` makes it (:52, :63-67)
  */
 int prl_segments_from_position_ids(const int64_t* pos, int64_t T, int32_t* seg_id, int64_t* seg_start,
                                    int32_t* n_seg, void* stream);

@@ -105,6 +105,36 @@ def _load_function(path: Path, func: str):
     return ns[func]
 
 
+def _load_compute_stats():
+    """`Tensors.compute_stats` of the reference (src/prime_rl/trainer/utils.py:235-256) compiled on its own and
+    bound to a plain defaultdict(list): the class's module needs packages the container lacks and its __init__
+    wants a process group.  Two stand-ins, neither touching the arithmetic: `flexible_all_gather` returns its
+    argument, which is what the reference's does on one rank (:203-204), and the device name the body moves the
+    values to is "cpu" here (no GPU in the build container; the constant is swapped in the syntax tree)."""
+    from collections import defaultdict
+
+    path = REF / "trainer/utils.py"
+    tree = ast.parse(path.read_text())
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "Tensors")
+    fn = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "compute_stats")
+
+    class _Cpu(ast.NodeTransformer):
+        def visit_Constant(self, node):
+            return ast.copy_location(ast.Constant("cpu"), node) if node.value == "cuda" else node
+
+    fn = ast.fix_missing_locations(_Cpu().visit(fn))
+    ns = {"torch": torch, "flexible_all_gather": lambda t: t}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), str(path), "exec"), ns)
+
+    def compute_stats(pieces: dict[str, list[torch.Tensor]]) -> dict[str, float]:
+        store = defaultdict(list)
+        for key, parts in pieces.items():
+            store[key].extend(parts)
+        return ns["compute_stats"](store)
+
+    return compute_stats
+
+
 def load_reference():
     _install_stubs()
     loss = _load("prime_rl.trainer.rl.loss", REF / "trainer/rl/loss.py")
@@ -424,6 +454,7 @@ def golden_lengths(grl) -> int:
         "starts_with_pad": [0, 0, 0, 1, 2, 0, 1, 2],
         "boundary_at_end": list(range(5)) + [0],
         "boundary_then_one_last": list(range(5)) + [0, 1],
+        "empty": [],  # boundaries = [0] and nothing else: ONE sample of length 0
         "len1": [0],
         "len2": [0, 1],
         "two_tokens_each": [0, 1, 0, 1, 0, 1],
@@ -448,6 +479,36 @@ def golden_lengths(grl) -> int:
         store[f"{name}__len"] = np.asarray(r, dtype=np.int64)
     np.savez_compressed(OUT / "response_lengths.npz", **store)
     return len(rows)
+
+
+def golden_tensor_stats(compute_stats) -> int:
+    """Logged statistics: the reference's `Tensors.compute_stats` on one rank against the oracle's `tensor_stats`
+    over the same values (a key's pieces concatenated)."""
+    gen = torch.Generator().manual_seed(7000)
+    cases: dict[str, list[torch.Tensor]] = {
+        "one_value": [torch.tensor([0.25])],  # std of one value is NaN
+        "two_values": [torch.tensor([3.0, -1.0])],  # even count: the LOWER middle value is the median
+        "ties": [torch.tensor([1.0, 1.0, 2.0, 2.0, 2.0, 1.0])],
+        "pieces": [torch.randn(n, generator=gen) for n in (5, 1, 300, 77)],
+        "probabilities": [torch.rand(2048, generator=gen), torch.rand(1999, generator=gen)],
+        "wide_range": [torch.randn(4097, generator=gen) * 1e4, torch.randn(3, generator=gen) * 1e-4],
+        "clipped_flags": [(torch.rand(1000, generator=gen) < 0.1).float()],
+        "with_inf": [torch.tensor([1.0, float("inf"), -2.0, 0.5])],
+        "negative_zero": [torch.tensor([-0.0, 0.0, -0.0])],
+    }
+    want = compute_stats({k: [p.clone() for p in v] for k, v in cases.items()})
+    store = {}
+    for name, parts in cases.items():
+        got = O.tensor_stats(torch.cat(parts))
+        for stat in ("mean", "median", "std", "min", "max"):
+            r, o = want[f"{name}/{stat}"], got[stat]
+            must(r == o or (r != r and o != o), f"tensor stats {name}/{stat}: {r} vs {o}")
+        store[f"{name}__sizes"] = np.asarray([p.numel() for p in parts], dtype=np.int64)
+        store[f"{name}__x"] = torch.cat(parts).numpy()
+        store[f"{name}__stats"] = np.asarray([want[f"{name}/{stat}"] for stat in ("mean", "median", "std", "min", "max")],
+                                             dtype=np.float64)
+    np.savez_compressed(OUT / "tensor_stats.npz", **store)
+    return len(cases)
 
 
 def golden_advantages(A) -> int:
@@ -540,6 +601,7 @@ def main() -> None:
         "lengths": golden_lengths(grl),
         "advantages": golden_advantages(A),
         "batches": golden_batches(B),
+        "tensor_stats": golden_tensor_stats(_load_compute_stats()),
     }
     print("oracle == reference on every case; fixtures written:", counts)
 

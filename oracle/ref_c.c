@@ -19,10 +19,10 @@
 #include <stdint.h>
 #include <stdlib.h>
 
-/* src/prime_rl/trainer/utils.py:50-69.  lengths has room for n entries; returns how many were written. */
+/* src/prime_rl/trainer/utils.py:50-69.  lengths has room for max(n, 1) entries; returns how many were written
+ * (an empty row is one sample of length 0: boundaries = [0] at :52). */
 int64_t prl_oracle_response_lengths(const int64_t* pos, int64_t n, int64_t* lengths) {
   int64_t count = 0, start = 0;
-  if (n == 0) return 0;
   for (int64_t i = 1; i < n; ++i) {
     if (pos[i] == 0 && pos[i - 1] != 0 && i + 1 < n && pos[i + 1] == 1) {
       lengths[count++] = i - start;

@@ -51,7 +51,9 @@ __global__ __launch_bounds__(kSegThreads) void k_segments(const int64_t* __restr
     __syncthreads();
   }
   if (tid == 0) {
-    const int n = T > 0 ? carry + 1 : 0;
+    // an empty row is ONE sample of length 0, as the reference's `boundaries = [0]` makes it
+    // (src/prime_rl/trainer/utils.py:52, :63-67)
+    const int n = carry + 1;
     n_seg[0] = n;
     seg_start[n] = T;
   }

@@ -290,14 +290,15 @@ def compute_loss(
 
 
 def segments_from_position_ids(position_ids: Tensor) -> tuple[Tensor, Tensor, Tensor]:
-    """seg_id int32 [T], seg_start int64 [T + 1], n_seg int32 [1], all on the
-    device and without a host round trip (rule of src/prime_rl/trainer/utils.py:36-69)."""
+    """seg_id int32 [T], seg_start int64 [max(T, 1) + 1], n_seg int32 [1], all on the
+    device and without a host round trip (rule of src/prime_rl/trainer/utils.py:36-69; an empty row is one
+    sample of length 0 there, so n_seg is never 0)."""
     dev = C.require_device(position_ids)
     lib = C.load()
     pos = position_ids.reshape(-1).to(torch.int64).contiguous()
     t = pos.numel()
     seg_id = torch.empty(t, dtype=torch.int32, device=dev)
-    seg_start = torch.empty(t + 1, dtype=torch.int64, device=dev)
+    seg_start = torch.empty(max(t, 1) + 1, dtype=torch.int64, device=dev)
     n_seg = torch.empty(1, dtype=torch.int32, device=dev)
     with C.on_device(dev), C.timed("prl_segments_from_position_ids", dev):
         C.check(

@@ -308,7 +308,10 @@ def test_empty_row():
     x = torch.zeros(1, 0, 100, device=DEV)
     idx = torch.zeros(1, 0, dtype=torch.long, device=DEV)
     assert prl.selective_log_softmax(x, idx).shape == (1, 0)
-    assert prl.get_response_lengths(torch.zeros(1, 0, dtype=torch.long, device=DEV)) == []
+    # one sample of length 0, as the reference's `boundaries = [0]` gives (src/prime_rl/trainer/utils.py:52-67)
+    assert prl.get_response_lengths(torch.zeros(1, 0, dtype=torch.long, device=DEV)) == [0]
+    seg_id, seg_start, n_seg = prl.segments_from_position_ids(torch.zeros(1, 0, dtype=torch.long, device=DEV))
+    assert seg_id.numel() == 0 and n_seg.item() == 1 and seg_start.tolist() == [0, 0]
     with pytest.raises(ValueError):
         prl.compute_loss([], [], [], [], prl.LossConfig(), 1.0)
 
@@ -442,6 +445,33 @@ def test_tensors_many_keys_many_pieces():
                 assert got[f"{key}/{name}"] == w[name], (key, name)
         assert abs(got[f"{key}/mean"] - w["mean"]) <= 1e-5 * max(1.0, abs(w["mean"]))
         assert abs(got[f"{key}/std"] - w["std"]) <= 1e-4 * w["std"]
+
+
+def test_tensors_against_reference_vectors():
+    """The logged statistics against what the reference's own `Tensors.compute_stats` returned for the same
+    values (tests/golden/tensor_stats.npz, made by oracle/make_golden.py from src/prime_rl/trainer/utils.py:235-256):
+    median, min and max bit for bit, mean and std to fp32 summation order (the device sums in double)."""
+    d = load_npz("tensor_stats.npz")
+    names = sorted(k[: -len("__x")] for k in d if k.endswith("__x"))
+    tensors = prl.Tensors()
+    for n in names:
+        x, at = d[n + "__x"].float(), 0
+        for size in d[n + "__sizes"].tolist():  # piece by piece, as the trainer records them
+            tensors.add(n, x[at:at + size].to(DEV))
+            at += size
+    got = tensors.compute_stats()
+    for n in names:
+        mean, median, std, lo, hi = d[n + "__stats"].tolist()
+        if n == "with_inf":  # mean and std of a set holding +inf: inf and NaN in the reference
+            assert got[f"{n}/max"] == hi and got[f"{n}/min"] == lo and got[f"{n}/median"] == median
+            assert got[f"{n}/mean"] == mean and math.isnan(got[f"{n}/std"]) and math.isnan(std)
+            continue
+        assert got[f"{n}/median"] == median and got[f"{n}/min"] == lo and got[f"{n}/max"] == hi, n
+        assert abs(got[f"{n}/mean"] - mean) <= 1e-5 * max(1.0, abs(mean)), n
+        if math.isnan(std):
+            assert math.isnan(got[f"{n}/std"]), n
+        else:
+            assert abs(got[f"{n}/std"] - std) <= 1e-4 * std + 1e-6, n
 
 
 def test_tensors_with_forty_keys_of_one_sign_each():

@@ -96,6 +96,18 @@ def test_response_lengths_vectors():
         assert O.get_response_lengths(d[n + "__pos"].unsqueeze(0)) == d[n + "__len"].tolist(), n
 
 
+def test_tensor_stats_vectors():
+    """`Tensors.compute_stats` of the reference (src/prime_rl/trainer/utils.py:235-256, one rank) on stored
+    values: the oracle's statistics are the reference's, bit for bit (NaN where the reference has NaN)."""
+    d = load_npz("tensor_stats.npz")
+    names = sorted(k[: -len("__x")] for k in d if k.endswith("__x"))
+    assert len(names) >= 9
+    for n in names:
+        got = O.tensor_stats(d[n + "__x"].float())
+        for stat, want in zip(("mean", "median", "std", "min", "max"), d[n + "__stats"].tolist()):
+            assert got[stat] == want or (got[stat] != got[stat] and want != want), (n, stat, got[stat], want)
+
+
 def test_advantage_vectors_and_docstring_answers():
     # src/prime_rl/orchestrator/advantage.py:13-16 and :27-30
     assert O.compute_advantages([0.0, 0.0, 1.0, 1.0], [1] * 4, 4, "drgrpo") == [-0.5, -0.5, 0.5, 0.5]
