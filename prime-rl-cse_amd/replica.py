@@ -333,6 +333,43 @@ _TENSOR_KEYS = ("input_ids", "position_ids", "advantages", "logprobs", "loss_mas
 _AUX_KEYS = ("logprobs", "entropy", "importance_ratio", "clipped_importance_ratio", "is_clipped", "n_seg")
 
 
+def arrival_hooks(model: nn.Module, params: list, bucket_of: list[int]) -> list[tuple[nn.Module, list[int]]]:
+    """(module, buckets to wait for before its forward) for the gather / forward overlap: the largest modules
+    whose parameters all lie in ONE bucket (a transformer block, the embedding, the final norm, the LM head), plus
+    every module that spans buckets and has parameters of its own, for those.  Only modules whose `forward` is
+    called can carry a hook: `nn.ModuleList` and `nn.ModuleDict` are containers the parent indexes into, their
+    forward never runs, so they are always descended through, also when everything below them shares a bucket
+    (all blocks of a small model in one bucket beside the table's)."""
+    index = {id(p): bucket_of[i] for i, p in enumerate(params)}
+    spans: dict[int, set[int]] = {}
+    out: list[tuple[nn.Module, list[int]]] = []
+
+    def span(m: nn.Module) -> set[int]:
+        if id(m) not in spans:
+            got = {index[id(p)] for p in m.parameters(recurse=False) if id(p) in index}
+            for c in m.children():
+                got |= span(c)
+            spans[id(m)] = got
+        return spans[id(m)]
+
+    def walk(m: nn.Module) -> None:
+        mine = span(m)
+        if not mine:
+            return
+        container = isinstance(m, (nn.ModuleList, nn.ModuleDict))
+        if len(mine) == 1 and not container:
+            out.append((m, sorted(mine)))
+            return
+        own = {index[id(p)] for p in m.parameters(recurse=False) if id(p) in index}
+        if own and not container:  # a module that spans buckets and has parameters of its own
+            out.append((m, sorted(own)))
+        for c in m.children():
+            walk(c)
+
+    walk(model)
+    return out
+
+
 class Replica:
     """The training side of one rank: model, flat state, optimizer and the micro-batch graphs."""
 
@@ -442,20 +479,10 @@ class Replica:
     # ------------------------------------------------------------------ the exchange inside backward
 
     def _hook_weight_arrival(self) -> None:
-        """A forward pre-hook on every module that is the largest one living in a single bucket (a transformer
-        block, the embedding, the final norm, the LM head): before it runs, the stream waits for that bucket's
-        all-gather of the previous step.  Later buckets are then still arriving while earlier ones compute."""
+        """A forward pre-hook on every module `arrival_hooks` names: before it runs, the stream waits for the
+        all-gathers of the previous step that carry its parameters.  Later buckets are then still arriving while
+        earlier ones compute."""
         st = self.state
-        index = {id(p): st.bucket_of[i] for i, p in enumerate(st.params)}
-        spans: dict[int, set[int]] = {}
-
-        def span(m: nn.Module) -> set[int]:
-            if id(m) not in spans:
-                out = {index[id(p)] for p in m.parameters(recurse=False) if id(p) in index}
-                for c in m.children():
-                    out |= span(c)
-                spans[id(m)] = out
-            return spans[id(m)]
 
         def wait_for(which: list[int]) -> Any:
             def hook(_module: nn.Module, _args: Any) -> None:
@@ -464,20 +491,8 @@ class Replica:
 
             return hook
 
-        def walk(m: nn.Module) -> None:
-            mine = span(m)
-            if not mine:
-                return
-            if len(mine) == 1:
-                m.register_forward_pre_hook(wait_for(sorted(mine)))
-                return
-            own = {index[id(p)] for p in m.parameters(recurse=False) if id(p) in index}
-            if own:  # a module that spans buckets and has parameters of its own
-                m.register_forward_pre_hook(wait_for(sorted(own)))
-            for c in m.children():
-                walk(c)
-
-        walk(self.model)
+        for module, which in arrival_hooks(self.model, st.params, st.bucket_of):
+            module.register_forward_pre_hook(wait_for(which))
 
     def _gradient_landed(self, i: int) -> None:
         """Post-accumulate hook of parameter `i` (runs on autograd's thread, on the stream of the pass).  Buckets

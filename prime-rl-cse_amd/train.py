@@ -227,16 +227,21 @@ def _train(config: RLTrainerConfig, world: Any, device: torch.device, mesh: Any)
         t_step = time.perf_counter()
         torch.cuda.reset_peak_memory_stats(device)  # the step's own peak, as src/prime_rl/trainer/rl/train.py:159
         t_save = 0.0
-        if replica is not None:
-            replica.wait_parameters()  # (all-gathers of the last step's weights may still be in flight)
         if step > 0 and publish and published < step:
             # weights of step N go to the inference side while step N + 1 trains (the whole-model trainer has
             # started this already, from inside step N: see `when_queued` below)
             t0 = time.perf_counter()
+            if replica is not None:
+                # the snapshot reads every parameter: all-gathers of the last step's weights may still be in
+                # flight.  (A step that publishes nothing does not wait here: its forward waits bucket by bucket,
+                # in the modules' pre-hooks, `replica.arrival_hooks`.)
+                replica.wait_parameters()
             publisher.publish(model, step)
             published = step
             t_save = time.perf_counter() - t0
         if logprob_model is not None:
+            if replica is not None:
+                replica.wait_parameters()  # the snapshot reads every parameter
             snapshots[step] = {k: v.detach().clone() for k, v in model.state_dict().items()}
         prepared = None
         if ahead:  # loaded and sorted while the last step's kernels were running

@@ -165,6 +165,43 @@ def test_bucket_plan_keeps_blocks_whole():
     assert [b - a for a, b in bucket_plan(names, numel, 2**26)] == [1] + [12] * 6 + [13]
 
 
+def test_weight_arrival_hooks_sit_on_modules_whose_forward_runs():
+    """The gather / forward overlap waits for a bucket in a forward pre-hook.  A hook on an `nn.ModuleList` never
+    fires (the parent indexes into it), so with the table in one bucket and ALL blocks in another, the blocks
+    themselves must carry the hooks; every bucket must be waited for by some module that is really called, and
+    every module with parameters must find its bucket on a hook at or above it."""
+    from prime_rl_cse_amd.replica import arrival_hooks
+
+    model = Blocks()
+    params = list(model.parameters())  # the tied head shares the table's parameter
+    names = [n for n, _ in model.named_parameters()]
+    for layout in ("table_and_blocks", "every_block_alone", "one_bucket"):
+        if layout == "table_and_blocks":
+            bucket_of = [0 if n == "model.embed_tokens.weight" else 1 for n in names]
+        elif layout == "every_block_alone":
+            bucket_of = [0 if n == "model.embed_tokens.weight" else
+                         1 + int(n.split(".")[2]) if n.startswith("model.layers.") else 6 for n in names]
+        else:
+            bucket_of = [0] * len(names)
+        hooks = arrival_hooks(model, params, bucket_of)
+        assert hooks and not any(isinstance(m, (nn.ModuleList, nn.ModuleDict)) for m, _ in hooks), layout
+        assert {k for _, which in hooks for k in which} == set(bucket_of), layout
+        hooked = {id(m): set(which) for m, which in hooks}
+        index = {id(p): bucket_of[i] for i, p in enumerate(params)}
+
+        def covered(module: nn.Module, above: set[int]) -> None:
+            above = above | hooked.get(id(module), set())
+            for p in module.parameters(recurse=False):
+                assert index[id(p)] in above, (layout, type(module).__name__)
+            for child in module.children():
+                covered(child, above)
+
+        covered(model, set())
+        if layout == "table_and_blocks":
+            blocks = [m for m, which in hooks if which == [1] and hasattr(m, "attn")]
+            assert len(blocks) == 5  # each block waits for the blocks' bucket itself
+
+
 def _bucketed_rank(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
