@@ -668,7 +668,12 @@ class _QKVNormRope(torch.autograd.Function):
         gw = torch.empty(2 * d, dtype=y.dtype, device=dev)
         # The three gradients as one matrix already (this package's attention kernels write them that way): the
         # kernel then works in place on the query and key blocks and the value block is where it belongs.
-        gy = _as_one_matrix(gq, gk, gv, t, hq, hk, d, y)
+        # In place only on gradients nobody else was handed: the caller (`qkv_norm_rope`) has named the outputs,
+        # and none of them carries a tensor hook, whose function receives these very tensors before this one runs
+        # and may have kept them.  (`retain_grad` keeps a copy of its own.)
+        refs = getattr(ctx, "prl_outputs", None)
+        watched = refs is None or any(z is not None and z._backward_hooks for z in (r() for r in refs))
+        gy = None if watched else _as_one_matrix(gq, gk, gv, t, hq, hk, d, y)
         in_place = gy is not None
         if not in_place:
             gy = torch.empty_like(y)
@@ -705,6 +710,19 @@ class _QKVNormRope(torch.autograd.Function):
         return dx, None, dw[0], dw[1], dw[2], gw[:d], gw[d:], None, None, None
 
 
+def qkv_norm_rope(x: Tensor, stacked: Tensor, wq: Tensor, wk: Tensor, wv: Tensor, nq: Tensor, nk: Tensor, cos: Tensor,
+                  sin: Tensor, eps: float) -> tuple[Tensor, Tensor, Tensor]:
+    """`_QKVNormRope.apply`, with the three outputs made known to the backward node: it works in place on their
+    gradients (when those arrive as the blocks of one matrix) only if it can see that no output carries a hook."""
+    import weakref
+
+    q, k, v = _QKVNormRope.apply(x, stacked, wq, wk, wv, nq, nk, cos, sin, eps)
+    node = q.grad_fn
+    if node is not None and node is k.grad_fn and node is v.grad_fn:
+        node.prl_outputs = tuple(weakref.ref(z) for z in (q, k, v))
+    return q, k, v
+
+
 def _fused_attention_forward(self: nn.Module, hidden_states: Tensor, position_embeddings: Any,
                              attention_mask: Tensor | None, past_key_values: Any = None, **kwargs: Any):
     """The forward of a transformers Qwen3-style attention block with the steps before the attention call taken
@@ -725,8 +743,8 @@ def _fused_attention_forward(self: nn.Module, hidden_states: Tensor, position_em
     if stacked is None or self.config._attn_implementation not in ALL_ATTENTION_FUNCTIONS \
             or not C.load().prl_qk_norm_rope_supported(C.dtype_code(x), self.head_dim):
         return self._prl_torch_forward(hidden_states, position_embeddings, attention_mask, past_key_values, **kwargs)
-    q, k, v = _QKVNormRope.apply(x, stacked, self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, qn.weight,
-                                 kn.weight, cos, sin, float(qn.variance_epsilon))
+    q, k, v = qkv_norm_rope(x, stacked, self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, qn.weight,
+                            kn.weight, cos, sin, float(qn.variance_epsilon))
     attend = ALL_ATTENTION_FUNCTIONS[self.config._attn_implementation]  # what the block's own forward looks up
     out, weights = attend(self, q, k, v, attention_mask, dropout=0.0 if not self.training else self.attention_dropout,
                           scaling=self.scaling, sliding_window=getattr(self, "sliding_window", None), **kwargs)

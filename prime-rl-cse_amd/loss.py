@@ -334,11 +334,6 @@ def unit_gradient(device: torch.device | str) -> Tensor:
     return t
 
 
-# which rows of the last sequence-mode call were left to the second pass (uint8 [T] on the device): for tests and
-# for looking at how often waits run out
-_LAST_SEQ_PENDING: list[Tensor | None] = [None]
-
-
 def _seq_rows_limits() -> tuple[int, int] | None:
     """(longest sample whose workgroups wait for each other, sweeps a workgroup waits) of the one-pass
     sequence-mode kernel, or None when it is switched off (PRL_SEQ_ROWS=0).  PRL_SEQ_ROWS_MAX_LEN (224: a launch
@@ -457,7 +452,7 @@ class _PolicyLoss(torch.autograd.Function):
                         "prl_logprob_bwd_selected",
                     )
             ctx.dlogits = dlogits
-            _LAST_SEQ_PENDING[0] = pending
+            ctx.seq_pending = pending  # which rows the second pass wrote: `policy_loss` hands it out in `aux`
         elif positions is not None:
             # the LM head ran only where the next token is scored: row r of the logits belongs to position
             # positions[r]; every per-token result still comes back in the packed row's layout
@@ -616,7 +611,7 @@ def policy_loss(
         logits, input_ids, position_ids, advantages, old_logprobs, loss_mask, float(temperature), loss_config,
         float(loss_scale), bool(skip_masked), positions, max_sample_len,
     )
-    return loss, {
+    aux = {
         "logprobs": lp,
         "entropy": ent,
         "importance_ratio": ratio,
@@ -625,6 +620,12 @@ def policy_loss(
         "seg_start": seg_start,
         "n_seg": n_seg,
     }
+    # one ratio per sample, gradient formed in the one-pass kernel: which rows it left to the second pass
+    # (uint8 [T] on the device; for tests and for looking at how often a row's wait runs out)
+    pending = getattr(loss.grad_fn, "seq_pending", None)
+    if pending is not None:
+        aux["seq_pending"] = pending
+    return loss, aux
 
 
 def scored_positions(loss_mask: Tensor, multiple: int = 1) -> Tensor:

@@ -104,7 +104,6 @@ class Bucket:
         self.gather_work: Any = None  # the all-gather in flight
         self.reduced = False          # this step's gradient sums of the bucket have been handed to the exchange
         self.held = False             # Replica: reduced only after the pass (the embedding table's gradient comes last)
-        self.pending = 0              # Replica: gradients of this pass still to land
         self.launched = False
         self.chunk_lo = self.chunk_hi = 0
 
@@ -333,6 +332,56 @@ _TENSOR_KEYS = ("input_ids", "position_ids", "advantages", "logprobs", "loss_mas
 _AUX_KEYS = ("logprobs", "entropy", "importance_ratio", "clipped_importance_ratio", "is_clipped", "n_seg")
 
 
+class ExchangeOrder:
+    """The order in which a rank hands its buckets to the gradient exchange.  Collectives must be issued in ONE
+    order on every rank, whatever order a rank's gradients land in and however many passes it runs: every
+    bucket that is not `held` goes back to front (a bucket only after all behind it), the held ones (the
+    embedding table's, whose second share exists only after the pass) front to back at the end.  `landed`
+    releases buckets from inside backward as far as that order allows; `finish` names what is left; a rank
+    without any pass issues `sequence()` as it stands."""
+
+    def __init__(self, held: list[bool]):
+        self.held = list(held)
+        self.pending = [0] * len(held)
+        self.launched = [False] * len(held)
+        self.next = -1
+
+    def sequence(self) -> list[int]:
+        n = len(self.held)
+        return [k for k in reversed(range(n)) if not self.held[k]] + [k for k in range(n) if self.held[k]]
+
+    def begin(self, pending: list[int]) -> None:
+        """`pending[k]`: how many gradients of bucket k this pass will deliver."""
+        self.pending = list(pending)
+        self.launched = [False] * len(self.held)
+        self.next = len(self.held) - 1
+
+    def landed(self, k: int) -> list[int]:
+        """A gradient of bucket k has arrived: the buckets to start now, in order."""
+        self.pending[k] -= 1
+        out = []
+        while self.next >= 0:
+            if self.held[self.next]:
+                self.next -= 1
+                continue
+            if self.pending[self.next] > 0:
+                break
+            out.append(self.next)
+            self.launched[self.next] = True
+            self.next -= 1
+        return out
+
+    def finish(self) -> tuple[list[int], list[int]]:
+        """After the pass: (buckets not yet started, back to front: some parameter got no gradient; the held
+        buckets, front to back)."""
+        n = len(self.held)
+        rest = [k for k in reversed(range(n)) if not self.launched[k] and not self.held[k]]
+        for k in rest:
+            self.launched[k] = True
+        self.next = -1
+        return rest, [k for k in range(n) if self.held[k]]
+
+
 def arrival_hooks(model: nn.Module, params: list, bucket_of: list[int]) -> list[tuple[nn.Module, list[int]]]:
     """(module, buckets to wait for before its forward) for the gather / forward overlap: the largest modules
     whose parameters all lie in ONE bucket (a transformer block, the embedding, the final norm, the LM head), plus
@@ -436,7 +485,7 @@ class Replica:
         self.overlap = st.exchange and len(st.buckets) > 1 and not graphs
         self._overlapping = False  # inside the last pass of a step
         self._first_form = False
-        self._next_bucket = -1
+        self._order = ExchangeOrder([])
         self._src = torch.zeros(len(st.params), dtype=torch.int64, device=self.device)
         self.bucket_launches = 0  # buckets handed to the exchange from inside a backward pass
         if self.overlap:
@@ -496,22 +545,14 @@ class Replica:
 
     def _gradient_landed(self, i: int) -> None:
         """Post-accumulate hook of parameter `i` (runs on autograd's thread, on the stream of the pass).  Buckets
-        go to the exchange back to front, each only after all behind it, so that every rank issues the same
-        collectives in the same order whatever order its gradients land in."""
+        go to the exchange in `ExchangeOrder`'s order, so that every rank issues the same collectives in the same
+        order whatever order its gradients land in."""
         if not self._overlapping:
             return
         st = self.state
-        st.buckets[st.bucket_of[i]].pending -= 1
-        while self._next_bucket >= 0:
-            b = st.buckets[self._next_bucket]
-            if b.held:
-                self._next_bucket -= 1
-                continue
-            if b.pending > 0:
-                break
-            self._launch_bucket(b)
+        for k in self._order.landed(st.bucket_of[i]):
+            self._launch_bucket(st.buckets[k])
             self.bucket_launches += 1
-            self._next_bucket -= 1
 
     def _launch_bucket(self, b: Bucket, reduce: bool = True) -> None:
         """Bucket `b`'s fresh gradients into the flat sums (one launch over the bucket's chunks) and, behind that
@@ -540,27 +581,42 @@ class Replica:
         self._overlapping = True
         self._first_form = self._starts_sums
         self._starts_sums = False
-        self._next_bucket = len(self.state.buckets) - 1
-        for b in self.state.buckets:
+        st = self.state
+        self._order = ExchangeOrder([b.held for b in st.buckets])
+        self._order.begin([sum(1 for p in st.params[b.first : b.last] if p.requires_grad) for b in st.buckets])
+        for b in st.buckets:
             b.launched = False
-            b.pending = sum(1 for p in self.state.params[b.first : b.last] if p.requires_grad)
 
     def _end_overlapped_pass(self, input_ids: Tensor, embed_grad: Tensor) -> None:
         """What backward's hooks have not started: buckets with a parameter that got no gradient, and the bucket
         of the embedding table, whose second share (the looked-up rows' gradient) only exists now."""
         self._overlapping = False
         st = self.state
-        for b in reversed(st.buckets):
-            if not b.launched and not b.held:
-                self._launch_bucket(b)
-        for b in st.buckets:
-            if b.held and not b.launched:
-                self._launch_bucket(b, reduce=False)
+        rest, held = self._order.finish()
+        for k in rest:
+            self._launch_bucket(st.buckets[k])
+        for k in held:
+            if not st.buckets[k].launched:
+                self._launch_bucket(st.buckets[k], reduce=False)
         self._embedding_backward(input_ids, embed_grad)
-        for b in st.buckets:
-            if b.held:
-                st.reduce_bucket(b)
+        for k in held:
+            st.reduce_bucket(st.buckets[k])
         self._first_form = False
+
+    def _exchange_broken(self) -> None:
+        """A pass that failed after some of its buckets went to the exchange: the peers are inside collectives
+        this rank will never complete.  The job is over either way (the launcher ends every rank once one has
+        exited, src/prime_rl/rl.py:641-651; `bench.launch_ranks` and torchrun do the same); aborting the
+        communicator, where torch offers it, makes the peers' pending collectives fail at once instead of after
+        the launcher's grace period."""
+        if not (dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        try:
+            from torch.distributed.distributed_c10d import _abort_process_group
+
+            _abort_process_group()
+        except Exception:  # older torch, or a backend without abort (gloo): the launcher's teardown remains
+            pass
 
     def _grad_pointers(self, grads: list, params: list | None = None) -> list[int]:
         dt = self.state.flat16.dtype
@@ -683,8 +739,12 @@ class Replica:
             self._begin_overlapped_pass()
             try:
                 loss, aux, grads, embed_grad = self._forward_backward(mb, plan, loss_config)
-            finally:
+            except BaseException:
                 self._overlapping = False
+                if any(b.launched for b in self.state.buckets):
+                    self._exchange_broken()
+                raise
+            self._overlapping = False
             del grads
             self._end_overlapped_pass(mb["input_ids"], embed_grad)
             del embed_grad
@@ -843,12 +903,8 @@ class Replica:
             if self.overlap:
                 # the other ranks start their reduce-scatters from inside a backward pass: every bucket but the
                 # embedding table's back to front, then that one; collectives have to come in one order everywhere
-                for b in reversed(self.state.buckets):
-                    if not b.held:
-                        self.state.reduce_bucket(b)
-                for b in self.state.buckets:
-                    if b.held:
-                        self.state.reduce_bucket(b)
+                for k in ExchangeOrder([b.held for b in self.state.buckets]).sequence():
+                    self.state.reduce_bucket(self.state.buckets[k])
             grad_norm = self.state.finish_step(self.optimizer, max_norm, keep_sums=not self.graphs,
                                                gathers_in_flight=self.overlap)
         if scheduler is not None:

@@ -9,6 +9,7 @@ hooks.
 
 from __future__ import annotations
 
+import os
 import statistics
 import time
 from pathlib import Path
@@ -39,7 +40,6 @@ def trainer_mode(config: RLTrainerConfig) -> str:
     `[model.compile]`, the reference's switch for its tracing compiler, and for FSDP2 by setting
     `model.reshard_after_forward` (either way: it then cares how FSDP2 treats its parameters); PRL_TRAINER
     overrides both.  Without any of these: auto."""
-    import os
 
     env = os.environ.get("PRL_TRAINER", "").lower()
     if env in ("replica", "fsdp", "auto"):
@@ -58,7 +58,6 @@ def replay_graphs(config: RLTrainerConfig) -> bool:
     pass of the 0.6B model, and replays of such nodes have gone wrong on MI355X boxes).  `[model.compile]` in a
     recipe, the reference's opt-in for its tracing compiler, selects the whole-model trainer
     (`trainer_mode`) but no longer graph replay: with a step's rows joined into one pass replay saved 1 %."""
-    import os
 
     if os.environ.get("PRL_GRAPHS", "") == "1":
         return True
@@ -72,7 +71,6 @@ def fused_blocks(config: RLTrainerConfig) -> bool:
     """Whether the transformer blocks run on this package's HIP kernels: when the recipe says
     `model.impl = "liger_kernel"` (the reference's switch for fused block kernels) and also when it says nothing;
     an explicit `impl = "hf"`, or PRL_BLOCKS=eager, keeps the transformers modules as they are."""
-    import os
 
     env = os.environ.get("PRL_BLOCKS", "").lower()
     if env in ("eager", "fused"):
@@ -203,15 +201,17 @@ def _train(config: RLTrainerConfig, world: Any, device: torch.device, mesh: Any)
     else:
         optimizer = replica.optimizer
     scheduler = setup_scheduler(optimizer, config.scheduler, config.max_steps, config.optim.lr)
+    # the weight files are a hand-off that lives for async_level + 1 steps and is read by torch.load only: their
+    # zip checksums are left out (PRL_SAVE_CRC32=1 keeps them)
     publisher = WeightPublisher(config.output_dir, config.weights.interval,
-                                config.ckpt.interval if config.ckpt else None, config.async_level, device)
+                                config.ckpt.interval if config.ckpt else None, config.async_level, device,
+                                crc32=os.environ.get("PRL_SAVE_CRC32", "0") == "1")
     loader = FakeDataLoader(config.data.fake) if config.data.fake else DataLoader(config.output_dir, 0)
     logprob_model = None
     if config.recompute_logprobs:
         logprob_model, _ = build_model(config, device, mesh, dtype=torch.bfloat16, for_training=False,
                                        shard=replica is None)
         logprob_model.requires_grad_(False)
-    import os
 
     publish = os.environ.get("PRL_PUBLISH", "1") != "0"  # 0: no weight files at all (to time the loop alone)
     snapshots: dict[int, dict[str, torch.Tensor]] = {}
@@ -319,7 +319,7 @@ def _train(config: RLTrainerConfig, world: Any, device: torch.device, mesh: Any)
         replica.wait_parameters()
     if step > 0 and publish and published < step:  # the final weights, as the orchestrator waits for them
         publisher.publish(model, step)
-    publisher.wait_all()
+    publisher.close()
     if config.bench and len(history) > 1:
         print_benchmark(history)
     return history

@@ -808,6 +808,20 @@ def setup_optimizer(model: nn.Module, lr: float = 1e-6, weight_decay: float = 0.
     return torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=weight_decay, betas=betas, fused=fused)
 
 
+def rccl_environment() -> None:
+    """What a process must have in its environment before RCCL builds a communicator between processes on the
+    MI355X nodes this package runs on: their host driver shares device memory between processes through dmabuf
+    handles only, and with the HSA runtime's legacy IPC mode RCCL's set-up (and any sharing of a device tensor
+    between processes) fails in `hipIpcGetMemHandle: invalid argument`.  The nodes' images export
+    HSA_ENABLE_IPC_MODE_LEGACY=0 for that reason; it is set here as well, unless the caller has set it, so that
+    a rank started with a scrubbed environment behaves the same.  Call before the first HIP call of the process
+    when possible (the runtime reads it at start-up); `bench.rank_commands` puts it into the ranks' environment
+    for that reason."""
+    import os
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
 def init_distributed(device: torch.device) -> Any:
     """RCCL process group (backend "nccl" on ROCm) and the 1-D data-parallel mesh
     (src/prime_rl/trainer/utils.py:27-33; dp_shard = world size as in
@@ -815,5 +829,6 @@ def init_distributed(device: torch.device) -> Any:
     from torch.distributed.device_mesh import init_device_mesh
 
     if not dist.is_initialized():
+        rccl_environment()
         dist.init_process_group("nccl", device_id=device)
     return init_device_mesh("cuda", (dist.get_world_size(),), mesh_dim_names=("dp_shard",))

@@ -108,6 +108,11 @@ class Tensors(defaultdict):
     a selection mask and an `exp` flag so that neither `x[mask]` (a host
     synchronisation) nor `torch.exp(x)` (an extra pass) has to be formed."""
 
+    # the keys the trainer logs (src/prime_rl/trainer/rl/train.py:313-333, :241-245), in the order every rank
+    # reduces them when there are several ranks
+    SHARED_KEYS = ("probs", "old_probs", "entropy", "loss", "importance_ratio", "clipped_importance_ratio",
+                   "is_clipped", "recomputed_logprob_error")
+
     def __init__(self):
         super().__init__(list)
         self._extra: dict[int, tuple[Tensor | None, int]] = {}
@@ -136,15 +141,22 @@ class Tensors(defaultdict):
         (2.01 vs 1.97 ms per bench step), so a single rank stays on the current
         stream.  PRL_STATS_STREAM=1 / =0 forces either.  The pieces are
         referenced by the returned object until `result()` has been called."""
-        keys = list(self.keys())
-        if not keys:
+        multi = dist.is_initialized() and dist.get_world_size() > 1
+        local = list(self.keys())
+        # Between ranks the scratch of ALL keys is all-reduced as one block per region, so every rank must reduce
+        # the same keys in the same order, also a rank that logged fewer of them this step (no row with a
+        # gradient, no recomputed log-probabilities): the trainer's keys in a fixed order, then whatever else
+        # was logged, sorted (such extra keys must then be logged on every rank).
+        keys = local if not multi else \
+            list(self.SHARED_KEYS) + sorted(k for k in local if k not in self.SHARED_KEYS)
+        if not keys or (not multi and not local):
             return StatsFuture([], None, None)
         lib = C.load()
         keep: list[Tensor] = []  # the pieces' storage must outlive the launches
         pieces = []
         dev = None
         for k, key in enumerate(keys):
-            for part in self.pop(key):
+            for part in (self.pop(key) if key in self else ()):
                 mask, op = self._extra.pop(id(part), (None, C.STAT_IDENTITY))
                 dev = C.require_device(part, mask)
                 x = part.reshape(-1).to(torch.float32).contiguous()
@@ -158,7 +170,8 @@ class Tensors(defaultdict):
         table = (C.StatPiece * max(n_pieces, 1))(*pieces)
         off = (C.c_int64 * 5)()
         C.check(lib.prl_stats_layout(n_keys, off), "prl_stats_layout")
-        multi = dist.is_initialized() and dist.get_world_size() > 1
+        if dev is None:  # a rank that logged nothing at all still takes part in the other ranks' all-reduces
+            dev = torch.device("cuda", torch.cuda.current_device())
         main = torch.cuda.current_stream(dev)
         side = _stats_stream(dev, multi)
         if side is not None:
@@ -180,14 +193,19 @@ class Tensors(defaultdict):
                             _all_reduce(ws.view(torch.float64)[off[1] // 8 : off[1] // 8 + 2 * n_keys],
                                         dist.ReduceOp.SUM)
                             _all_reduce(i32[off[2] // 4 : off[2] // 4 + 2 * n_keys], dist.ReduceOp.MAX)
-                C.check(lib.prl_stats_finish(C.ptr(ws), n_keys, C.ptr(out), None, st), "prl_stats_finish")
+                counts = torch.empty(n_keys, dtype=torch.int64, device=dev) if multi else None
+                C.check(lib.prl_stats_finish(C.ptr(ws), n_keys, C.ptr(out), C.ptr(counts), st), "prl_stats_finish")
             host = torch.empty((n_keys, 5), dtype=torch.float32, pin_memory=True)
             host.copy_(out, non_blocking=True)
+            host_counts = None
+            if multi:
+                host_counts = torch.empty(n_keys, dtype=torch.int64, pin_memory=True)
+                host_counts.copy_(counts, non_blocking=True)
             done = torch.cuda.Event()
             done.record(torch.cuda.current_stream(dev))
         # the launches hold raw pointers into the pieces, `ws` and `out`: the future keeps all of them alive until
         # the copy-out has been seen to finish
-        return StatsFuture(keys, host, done, keep + [ws, out])
+        return StatsFuture(keys, host, done, keep + [ws, out, counts], host_counts, set(local))
 
 
 _STATS_STREAMS: dict[int, Any] = {}
@@ -211,8 +229,10 @@ def _stats_stream(dev: torch.device, multi: bool):
 class StatsFuture:
     """The pending result of `Tensors.compute_stats_async`."""
 
-    def __init__(self, keys: list[str], host: Tensor | None, done: "torch.cuda.Event | None", keep: Any = None):
+    def __init__(self, keys: list[str], host: Tensor | None, done: "torch.cuda.Event | None", keep: Any = None,
+                 counts: Tensor | None = None, local: set[str] | None = None):
         self._keys, self._host, self._done, self._keep = keys, host, done, keep
+        self._counts, self._local = counts, local
 
     def result(self) -> dict[str, float]:
         if self._host is None:
@@ -220,7 +240,10 @@ class StatsFuture:
         self._done.synchronize()  # the one host wait of the step's statistics
         self._keep = None
         metrics: dict[str, float] = {}
-        for key, row in zip(self._keys, self._host.tolist()):
+        counts = None if self._counts is None else self._counts.tolist()
+        for i, (key, row) in enumerate(zip(self._keys, self._host.tolist())):
+            if counts is not None and counts[i] == 0 and key not in self._local:
+                continue  # one of the shared keys that no rank logged this step
             for name, val in zip(STAT_NAMES, row):
                 metrics[f"{key}/{name}"] = val
         return metrics

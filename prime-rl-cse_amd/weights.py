@@ -101,20 +101,23 @@ class WeightPublisher:
     """Publishes HF-compatible bf16 weight files without stalling the step."""
 
     def __init__(self, output_dir: Path, interval: int | None = None, ckpt_interval: int | None = None,
-                 async_level: int = 2, device: torch.device | str | None = None, max_in_flight: int = 3):
+                 async_level: int = 2, device: torch.device | str | None = None, max_in_flight: int = 3,
+                 crc32: bool = True):
         """`max_in_flight` publications may be on their way to the disk at once; a further `publish` first waits
         for the oldest (steps faster than the disk would otherwise pile up pinned host copies of the weights
         without bound, and pinning fresh host memory for every publication costs more than the copy itself:
         ~100 ms per 3 GB).  Three writers keep up with a publication every ~90 ms for a 1.2 GB model (two: 135 ms;
-        more than three gain nothing, `tools/publish_profile.py`)."""
-        self.max_in_flight = max(1, int(max_in_flight))
-        # torch.save of a 1.2 GB model takes 267 ms, 118 ms without the zip records' CRC32, which torch.load
-        # (what the inference worker and transformers read these files with) never looks at; other zip tools may
-        # complain about its absence.  The files are a hand-off that lives for async_level + 1 steps, so the
-        # checksum is left out (process-wide: torch has one switch) unless PRL_SAVE_CRC32=1 asks for it.
-        import os
+        more than three gain nothing, `tools/publish_profile.py`).
 
-        if os.environ.get("PRL_SAVE_CRC32", "0") != "1" and hasattr(torch.serialization, "set_crc32_options"):
+        `crc32=False` leaves the zip records' CRC32 out of the files: torch.save of a 1.2 GB model takes 267 ms
+        with it and 118 ms without, and torch.load (what the inference worker and transformers read these files
+        with) never looks at it; other zip tools may complain about its absence.  torch has ONE switch for the
+        whole process, so this publisher turns it off for as long as it lives and `close()` puts back what it
+        found; the default leaves torch's setting alone."""
+        self.max_in_flight = max(1, int(max_in_flight))
+        self._crc32_before: bool | None = None
+        if not crc32 and hasattr(torch.serialization, "set_crc32_options"):
+            self._crc32_before = bool(torch.serialization.get_crc32_options())
             torch.serialization.set_crc32_options(False)
         self.weights_dir = get_weights_dir(output_dir)
         self.interval, self.ckpt_interval, self.async_level = interval, ckpt_interval, async_level
@@ -332,6 +335,13 @@ class WeightPublisher:
         for t in self._cleaners:
             t.join()
         self._cleaners = []
+
+    def close(self) -> None:
+        """Every publication written, every clean-up done, and torch's CRC32 switch as this publisher found it."""
+        self.wait_all()
+        if self._crc32_before is not None:
+            torch.serialization.set_crc32_options(self._crc32_before)
+            self._crc32_before = None
 
     # ------------------------------------------------------------------ clean-up
 

@@ -9,6 +9,7 @@ import sys
 import time
 from pathlib import Path
 
+import pytest
 import torch
 
 REPO = Path(__file__).resolve().parent.parent
@@ -28,18 +29,22 @@ def test_rank_commands_carry_the_rendezvous_of_one_node():
         assert env["HOME"] == "/x" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
-def test_two_ranks_meet_over_gloo_and_one_line_comes_out():
+@pytest.mark.parametrize("n", [2, 8])
+def test_ranks_meet_over_gloo_and_one_line_comes_out(n):
+    """`python bench.py --gpus N --launch-check` as the driver starts it for N = 2 and for the whole node's 8:
+    the parent starts the ranks, they rendezvous (gloo here: no GPU), all-reduce one number, and exactly one
+    line reaches stdout."""
     env = {**os.environ, "PRL_BENCH_BACKEND": "gloo"}
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    out = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--launch-check"], env=env,
-                         capture_output=True, text=True, timeout=240)
+    out = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", str(n), "--launch-check"], env=env,
+                         capture_output=True, text=True, timeout=400)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [x for x in out.stdout.splitlines() if x.strip()]
     assert len(lines) == 1  # rank 0's line and nothing else on stdout
     line = json.loads(lines[0])
-    assert line["ranks"] == 2 and line["n_gpus"] == 2 and line["value"] == 1.0  # ranks 0 + 1
-    assert line["devices"] == ["rank 0: cpu", "rank 1: cpu"]
+    assert line["ranks"] == n and line["n_gpus"] == n and line["value"] == float(n * (n - 1) // 2)  # sum of ranks
+    assert line["devices"] == [f"rank {r}: cpu" for r in range(n)]
     assert line["gpu_initialised"] is False
 
 

@@ -482,16 +482,40 @@ def test_qk_norm_rope_backward_in_place_on_gradients_that_are_one_matrix(dtype):
     assert _as_one_matrix(together[0], together[2], together[1], t, hq, hk, d,
                           torch.empty(t, (hq + 2 * hk) * d, dtype=dtype, device=DEV)) is None
 
-    def run(gs):
+    def run(gs, hook=False, retain=False):
         xs = x.clone().requires_grad_(True)
         wq, wk, wv = (p.detach().requires_grad_(True) for p in w.split([hq * d, hk * d, hk * d]))
         a, b = nq.clone().requires_grad_(True), nk.clone().requires_grad_(True)
-        out = _QKVNormRope.apply(xs, fused.adjacent_rows(wq, wk, wv), wq, wk, wv, a, b, cos, sin, 1e-6)
+        out = fused.qkv_norm_rope(xs, fused.adjacent_rows(wq, wk, wv), wq, wk, wv, a, b, cos, sin, 1e-6)
+        seen = []
+        if hook:
+            out[0].register_hook(lambda g: seen.append(g))  # a holder of the very tensor the backward is handed
+        if retain:
+            out[1].retain_grad()
         torch.autograd.backward(list(out), list(gs))
-        return [z.grad for z in (xs, wq, wk, wv, a, b)]
+        return [z.grad for z in (xs, wq, wk, wv, a, b)], seen, out[1].grad if retain else None
 
-    for got, want in zip(run(together), run(grads)):
-        assert torch.equal(got, want)
+    want, _, _ = run(grads)
+    before = [g.clone() for g in together]
+    got, _, _ = run(together)
+    for a_, b_ in zip(got, want):
+        assert torch.equal(a_, b_)
+    assert not torch.equal(together[0], before[0])  # nobody was watching: the kernel worked in place
+    # with a hook on an output the gradients are left as they arrived, and the hook's tensor keeps dq
+    for dst, src in zip(together, grads):
+        dst.copy_(src)
+    got, seen, kept = run(together, hook=True, retain=True)
+    for a_, b_ in zip(got, want):
+        assert torch.equal(a_, b_)
+    assert torch.equal(seen[0], grads[0]) and torch.equal(kept, grads[1])
+    for g, src in zip(together, grads):
+        assert torch.equal(g, src)
+    # the bare function (no outputs named) never works in place
+    out = _QKVNormRope.apply(x.clone().requires_grad_(True), w, *w.split([hq * d, hk * d, hk * d]), nq, nk, cos, sin,
+                             1e-6)
+    torch.autograd.backward(list(out), list(together))
+    for g, src in zip(together, grads):
+        assert torch.equal(g, src)
 
 
 def test_weight_gradient_split_over_the_tokens():

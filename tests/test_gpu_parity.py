@@ -543,6 +543,58 @@ def test_tensors_across_ranks_without_gathering():
             assert abs(got[f"{k}/std"] - w["std"]) <= 1e-4 * w["std"]
 
 
+def _uneven_stats_rank(rank, world, port, q):
+    import os
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        gen = torch.Generator().manual_seed(900 + rank)
+        tensors = prl.Tensors()
+        mine = {}
+        # rank 0 logs three of the trainer's keys, rank 1 one of them, rank 2 nothing at all (no row with a
+        # gradient this step), rank 3 two of them, in another order than rank 0
+        keys = {0: ("probs", "entropy", "loss"), 1: ("entropy",), 2: (), 3: ("loss", "probs")}[rank]
+        for key in keys:
+            n = 400 + 150 * rank
+            x = torch.randn(n, generator=gen) * (1 + rank)
+            tensors.add(key, x.to(DEV))
+            mine[key] = x
+        got = tensors.compute_stats()
+        q.put((rank, got, {k: v.tolist() for k, v in mine.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_that_log_different_keys_still_reduce_together():
+    """Four ranks (gloo, sharing the one GPU) that logged different subsets of the trainer's keys, one of them
+    nothing: every rank takes part in the same all-reduces (a fixed key order), gets the statistics of the
+    union, and keys that nobody logged do not appear."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_uneven_stats_rank, args=(r, 4, 29741, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    logged = {"probs", "entropy", "loss"}
+    union = {k: torch.tensor(sum((r[2].get(k, []) for r in sorted(results)), [])) for k in logged}
+    for _, got, _ in results:
+        assert {k.split("/")[0] for k in got} == logged
+        for k, vals in union.items():
+            w = O.tensor_stats(vals)
+            for name in ("median", "min", "max"):
+                assert got[f"{k}/{name}"] == w[name]
+            assert abs(got[f"{k}/mean"] - w["mean"]) <= 1e-5
+            assert abs(got[f"{k}/std"] - w["std"]) <= 1e-4 * w["std"]
+
+
 # --------------------------------------------------------------------------- more corners of the boundary
 
 

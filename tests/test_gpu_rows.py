@@ -369,7 +369,7 @@ def test_sequence_rows_kernel_full_size_through_policy_loss(monkeypatch):
     dl = logits.to(DEV).requires_grad_(True)
     loss, aux = prl.policy_loss(dl, b(ids).to(DEV), b(pos).to(DEV), b(adv).to(DEV), b(old).to(DEV), b(mask).to(DEV),
                                 1.0, cfg, len(lengths), skip_masked=True)
-    pending = L._LAST_SEQ_PENDING[0].cpu().bool()
+    pending = aux["seq_pending"].cpu().bool()
     loss.backward()
     n = len(lengths)
     assert int(aux["n_seg"].item()) == n
@@ -433,12 +433,11 @@ def test_sequence_mode_with_a_long_sample_announced_takes_the_two_passes():
     b = lambda x: x.unsqueeze(0)
     want = O.policy_epilogue(logits, b(ids), b(pos), b(adv), b(old), b(mask), 1.0, cfg, len(lengths))
     for hint, one_pass in ((300, False), (None, True), (200, True)):
-        L._LAST_SEQ_PENDING[0] = None
         dl = logits.to(DEV).requires_grad_(True)
         loss, aux = prl.policy_loss(dl, b(ids).to(DEV), b(pos).to(DEV), b(adv).to(DEV), b(old).to(DEV),
                                     b(mask).to(DEV), 1.0, cfg, len(lengths), max_sample_len=hint)
         loss.backward()
-        assert (L._LAST_SEQ_PENDING[0] is not None) == one_pass
+        assert ("seq_pending" in aux) == one_pass
         close(loss, want["loss"])
         close(aux["importance_ratio"][: len(lengths)], want["importance_ratio"])
         assert bf16_ulp_close(dl.grad.cpu(), want["dlogits"], ulps=1, atol=1e-9)

@@ -202,6 +202,40 @@ def test_weight_arrival_hooks_sit_on_modules_whose_forward_runs():
             assert len(blocks) == 5  # each block waits for the blocks' bucket itself
 
 
+def test_every_rank_issues_its_buckets_in_one_order():
+    """Collectives have to be issued in the same order on every rank.  Whatever order a busy rank's gradients
+    land in, with parameters that get no gradient at all, and on a rank that runs no pass, the buckets go to
+    the exchange in `ExchangeOrder.sequence()`: not-held buckets back to front, the held one(s) last."""
+    import random
+
+    from prime_rl_cse_amd.replica import ExchangeOrder
+
+    rnd = random.Random(5)
+    for trial in range(200):
+        n = rnd.randint(1, 9)
+        held = [k == 0 and rnd.random() < 0.8 for k in range(n)]  # the table's bucket is the first one
+        sizes = [rnd.randint(1, 6) for _ in range(n)]
+        idle = ExchangeOrder(held).sequence()
+        assert sorted(idle) == list(range(n))
+        order = ExchangeOrder(held)
+        order.begin(sizes)
+        # gradients of every bucket in random order; some parameters never get one
+        events = [k for k in range(n) for _ in range(sizes[k]) if rnd.random() < 0.85]
+        rnd.shuffle(events)
+        issued = []
+        for k in events:
+            now = order.landed(k)
+            assert all(not held[j] for j in now)
+            issued += now
+        rest, last = order.finish()
+        assert issued + rest + last == idle, (trial, held, sizes, events)
+    # every gradient landed, back to front: everything but the held bucket leaves from inside backward
+    order = ExchangeOrder([True, False, False])
+    order.begin([1, 2, 1])
+    assert order.landed(2) == [2] and order.landed(1) == [] and order.landed(0) == [] and order.landed(1) == [1]
+    assert order.finish() == ([], [0])
+
+
 def _bucketed_rank(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
@@ -218,13 +252,23 @@ def _bucketed_rank(rank, world, port, q):
                 opt = torch.optim.AdamW(state.holder().parameters(), lr=1e-2, weight_decay=0.01)
                 grads = _grads(20 + rank, model)
                 norms, means = [], []
+                # ranks differ in how many passes make up their step (1, 2 or 3 accumulations of a share of the
+                # gradient), and with more than two ranks the last one has nothing to learn from at all
+                passes = rank % 3 + 1
+                idle = world > 2 and rank == world - 1
                 for s in range(3):
-                    for g, o, n in zip(grads, state.offsets, state.numel):
-                        state.acc32[o : o + n] += g.reshape(-1) * (s + 1)
+                    if not idle:
+                        for _ in range(passes):
+                            for g, o, n in zip(grads, state.offsets, state.numel):
+                                state.acc32[o : o + n] += g.reshape(-1) * ((s + 1) / passes)
                     if bucket_bytes is not None and s == 1:
-                        # as backward's hooks do it: buckets handed over early, back to front, the first one last
-                        for b in reversed(state.buckets[1:]):
-                            state.reduce_bucket(b)
+                        # as backward's hooks do it, and as a rank without a pass does it: the order of
+                        # `ExchangeOrder` (buckets handed over early, back to front, the table's last)
+                        from prime_rl_cse_amd.replica import ExchangeOrder
+
+                        held = [k == 0 for k in range(len(state.buckets))]
+                        for k in ExchangeOrder(held).sequence()[:-1]:
+                            state.reduce_bucket(state.buckets[k])
                     state.wait_reduced()
                     mean = torch.zeros(state.total)
                     for lo, hi, at in state.owned_ranges():
@@ -241,7 +285,11 @@ def _bucketed_rank(rank, world, port, q):
                     both = (x != 0) & (y != 0)  # (each layout gives this rank other elements)
                     assert torch.equal(x[both], y[both])
             same_weights = all(torch.equal(p1, p2) for p1, p2 in zip(m1.parameters(), m2.parameters()))
-            close = all(torch.allclose(p1, p2, rtol=1e-6, atol=1e-7) for p1, p2 in zip(m1.parameters(), m2.parameters()))
+            # "to rounding": another order of adding the ranks' shares moves a mean gradient in its last bit, and
+            # AdamW turns that into a visible step only where the shares nearly cancel (update = lr * g / |g|
+            # early on): all but a handful of elements within 1e-6, none further than a hundredth of one step
+            diff = torch.cat([(p1 - p2).abs().reshape(-1) for p1, p2 in zip(m1.parameters(), m2.parameters())])
+            close = bool(diff.max() < 1e-4) and float((diff > 1e-6).float().mean()) < 5e-3
             # master shard against the compute copy (fp32 here): the same numbers
             for lo, hi, at in many.owned_ranges():
                 assert torch.equal(many.master.detach()[at : at + hi - lo], many.flat16[lo:hi])
@@ -254,9 +302,9 @@ def _bucketed_rank(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@__import__("pytest").mark.parametrize("world", [2, 4])
+@__import__("pytest").mark.parametrize("world", [2, 4, 8])
 def test_bucketed_exchange_gives_the_step_of_the_single_exchange_over_gloo(world):
-    """Two and four ranks: the flat state cut into buckets (each sharded over the ranks by itself, some reduced early)
+    """Two, four and eight ranks (each with its own number of passes per step, one of them idle): the flat state cut into buckets (each sharded over the ranks by itself, some reduced early)
     against the one-bucket layout.  With two ranks and no clipping the updated weights agree bit for bit (every
     element sees the same mean gradient, a + b in either order, and the same AdamW arithmetic); the gradient norm
     is a sum in another order, so with clipping the weights agree to rounding.  With four ranks the collective

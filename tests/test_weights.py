@@ -42,6 +42,22 @@ def test_publish_writes_reference_layout(tmp_path):
             assert torch.equal(state[k], v)
 
 
+def test_crc32_switch_is_explicit_and_put_back(tmp_path):
+    """torch has one process-wide switch for the zip records' CRC32.  A publisher leaves it alone unless asked
+    (`crc32=False`), and `close()` restores what it found."""
+    reset_world()
+    before = torch.serialization.get_crc32_options()
+    pub = WeightPublisher(tmp_path / "a", async_level=1)
+    assert torch.serialization.get_crc32_options() == before
+    pub.close()
+    fast = WeightPublisher(tmp_path / "b", async_level=1, crc32=False)
+    assert torch.serialization.get_crc32_options() is False
+    path = fast.publish(Tiny(), step=1).wait(timeout=30)
+    assert set(torch.load(path, weights_only=True)) == set(Tiny().state_dict())  # torch.load does not need it
+    fast.close()
+    assert torch.serialization.get_crc32_options() == before
+
+
 def test_keep_and_clean_rule(tmp_path):
     # src/prime_rl/trainer/weights.py:211-228: consider step - (async_level + 1); keep evaluation steps and the
     # async_level + 1 steps that lead up to a full checkpoint
@@ -270,6 +286,74 @@ def test_weight_broadcast_between_trainer_and_inference_ranks_over_gloo():
         assert p.exitcode == 0
     assert out[0] == "sent" and out[1] == "skipped"
     assert out[2] == [(3, True), (4, True), (5, True)]
+
+
+def _broadcast_rank_of_eight(rank, world, port, q):
+    import os
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+
+    import prime_rl_cse_amd as prl
+    from prime_rl_cse_amd.weights import WeightBroadcast
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    prl.reset_world()
+    try:
+        # a node of eight: ranks 0-3 train (0 publishes), ranks 4-7 serve; the channel is {0, 4, 5, 6, 7}
+        members = [0, 4, 5, 6, 7]
+        group = dist.new_group(members)  # every rank makes the call, members or not
+        ch = WeightBroadcast(group if rank in members else None, src=0, device="cpu")
+
+        def weights(step):
+            g = torch.Generator().manual_seed(step)
+            return {"embed.weight": torch.randn(33, 16, generator=g).to(torch.bfloat16),
+                    "layers.0.w": torch.randn(16, 16, generator=g).to(torch.bfloat16),
+                    "norm.weight": torch.randn(16, generator=g).to(torch.bfloat16)}
+
+        if rank in (1, 2, 3):
+            ch.is_member = False
+            ch.send(weights(1), 1)  # a trainer rank outside the channel: returns at once
+            q.put((rank, "skipped"))
+        elif rank == 0:
+            for step in (1, 2, 3, 4):
+                ch.send(weights(step), step)
+            ch.close()
+            q.put((rank, "sent"))
+        else:
+            got = []
+            while True:
+                r = ch.receive()
+                if r is None:
+                    break
+                step, state = r
+                want = weights(step)
+                got.append((step, set(state) == set(want) and all(torch.equal(state[k], want[k]) for k in want)))
+            q.put((rank, got))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_weight_broadcast_to_four_inference_ranks_of_an_eight_rank_node_over_gloo():
+    """Four trainer ranks and four receiving ranks in one job: the publishing rank's flat buckets reach every
+    receiver, publication after publication, and the other trainer ranks are not held up."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31000 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_broadcast_rank_of_eight, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=240) for _ in range(8))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert out[0] == "sent" and all(out[r] == "skipped" for r in (1, 2, 3))
+    for r in (4, 5, 6, 7):
+        assert out[r] == [(1, True), (2, True), (3, True), (4, True)], (r, out[r])
 
 
 @pytest.mark.gpu

@@ -51,12 +51,14 @@ def main() -> None:
     variants = {"two passes": "0", "one pass": "1"}
     count = [0]
 
+    last_aux = [None]
+
     def run(flag: str) -> None:
         os.environ["PRL_SEQ_ROWS"] = flag
         x = bufs[count[0] % 3].requires_grad_(True)
         count[0] += 1
         x.grad = None
-        loss, _ = prl.policy_loss(x, ids, pos, adv, old, mask, 1.0, cfg, n_samples)
+        loss, last_aux[0] = prl.policy_loss(x, ids, pos, adv, old, mask, 1.0, cfg, n_samples)
         loss.backward(unit)
 
     times = {k: [] for k in variants}
@@ -77,7 +79,7 @@ def main() -> None:
     run("1")
     torch.cuda.synchronize()
     print(f"{'ragged samples of 11-128' if ragged else 'samples of ' + str(length)} tokens; rows left to the second pass in the last one-pass call: "
-          f"{int(L._LAST_SEQ_PENDING[0].sum())} of {t}")
+          f"{int(last_aux[0]['seq_pending'].sum())} of {t}")
     for k, ts in sorted(times.items(), key=lambda kv: statistics.median(kv[1])):
         print(f"{k:12s} median {statistics.median(ts) * 1e3:7.1f} us  min {min(ts) * 1e3:7.1f} us", flush=True)
 

@@ -24,7 +24,7 @@ for it in range(60):
         loss, aux = prl.policy_loss(x, ids.to(dev), pos.to(dev), adv, old, mask.to(dev), 0.9, cfg, len(lens), skip_masked=bool(it % 3))
         loss.backward()
         outs.append((loss.item(), aux["logprobs"].cpu(), x.grad.cpu()))
-    pend += int(L._LAST_SEQ_PENDING[0].sum())
+    pend += int(aux["seq_pending"].sum())
     (l0, p0, g0), (l1, p1, g1) = outs
     ok = abs(l0 - l1) <= 1e-5 * max(1, abs(l0)) and (p0 - p1).abs().max() < 1e-5 and bf16_ulp_close(g1, g0, ulps=1, atol=1e-10)
     if not ok:

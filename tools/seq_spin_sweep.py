@@ -55,12 +55,12 @@ for kind in ("ragged", "200"):
             x.grad = None
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            loss, _ = prl.policy_loss(x, ids, pos, adv, old, mask, 1.0, cfg, 16.0)
+            loss, aux = prl.policy_loss(x, ids, pos, adv, old, mask, 1.0, cfg, 16.0)
             loss.backward(unit)
             b.record()
             torch.cuda.synchronize()
             if rep >= 2:
                 times.append(a.elapsed_time(b) * 1e3)
-                pend.append(int(L._LAST_SEQ_PENDING[0].sum()))
+                pend.append(int(aux["seq_pending"].sum()))
         print(f"samples {kind:7s} spin limit {spins:5d}: rows left to the second pass {min(pend):4d}..{max(pend):4d} of {t}, "
               f"{statistics.median(times):6.1f} us", flush=True)
