@@ -33,7 +33,6 @@ constexpr int kBM = 256, kBN = 256, kBK = 64;
 constexpr int kGemmThreads = 512;
 constexpr int kQuarterBytes = 16384;         // 128 rows x 64 k, or 64 k x 128 columns, of bf16
 constexpr int kStageBytes = 4 * kQuarterBytes;  // P half 0 | P half 1 | Q half 0 | Q half 1
-constexpr int kSuperM = 8, kSuperN = 4;      // tiles of C that one XCD's 32 compute units work on together
 
 enum { kOutBf16 = 0, kOutF32Slab = 1, kOutBf16Transposed = 2 };
 
@@ -45,11 +44,14 @@ struct GemmArgs {
   int64_t slab_stride;  // elements between the fp32 slabs of two K splits
   int M, N;
   int ktiles;            // K / 64
-  int ktiles_per_split;  // K-tiles one workgroup walks
+  int ktiles_per_split;  // K-tiles one work item walks
   int nsplit;
-  int mtiles, ntiles;  // ceil(M / 256), ceil(N / 256)
-  int super_m, super_n;  // ceil(mtiles / 8), ceil(ntiles / 4)
-  int stagger_ticks;     // 0, or one tile's duration in ticks of the 100 MHz clock (see k_lm_gemm)
+  int mtiles, ntiles;    // ceil(M / 256), ceil(N / 256)
+  int super_log2;        // a super-tile is (1 << super_log2) x (32 >> super_log2) tiles of C
+  int super_m, super_n;  // super-tiles along M and N
+  int total_items;       // 256 * ceil(super_m * super_n * nsplit / 8): work items, valid or not
+  int skew_ticks;        // workgroup b starts (b's rank among 256) / 256 * skew_ticks of the 100 MHz clock late
+  unsigned long long* stamps;  // diagnostic builds only (PRL_GEMM_STAMPS): 8 clock readings per work item, or NULL
 };
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
@@ -87,55 +89,83 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-// Which tile and K split a workgroup of the 1-D grid takes.  Workgroup b runs on XCD b % 8; an XCD's 32 compute
-// units take one "super-tile" of 8 x 4 tiles of C of one K split at a time, so that the operand panels they share
-// are read from memory once and from that XCD's L2 afterwards.
-__device__ __forceinline__ bool gemm_item(const GemmArgs& a, int& mt, int& nt, int& split) {
-  const int id = (int)blockIdx.x, xcd = id & 7, slot = id >> 3;
+// Which tile and K split work item `item` is.  The kernel is persistent: 256 workgroups, one per compute unit,
+// workgroup b taking the items b, b + 256, ...  Workgroup b runs on XCD b % 8 (so do all its items), and the 32
+// items an XCD's compute units work on at a time are one "super-tile" of 8 x 4 (or 4 x 8, ... as the tile
+// counts allow) tiles of C of one K split, so that the operand panels they share are read from memory once and
+// from that XCD's L2 afterwards.  False: padding at the edge of a super-tile.
+__device__ __forceinline__ bool gemm_item(const GemmArgs& a, int item, int& mt, int& nt, int& split) {
+  const int xcd = item & 7, slot = item >> 3;
   const int sid = (slot >> 5) * 8 + xcd, within = slot & 31;
   const int per_split = a.super_m * a.super_n;
   if (sid >= per_split * a.nsplit) return false;
   split = sid / per_split;
   const int s = sid - split * per_split;
   const int sm = s % a.super_m, sn = s / a.super_m;
-  mt = sm * kSuperM + (within & (kSuperM - 1));
-  nt = sn * kSuperN + (within >> 3);
+  mt = (sm << a.super_log2) + (within & ((1 << a.super_log2) - 1));
+  nt = sn * (32 >> a.super_log2) + (within >> a.super_log2);
   return mt < a.mtiles && nt < a.ntiles;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {  // all but the wave's N youngest vector-memory operations are done
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// stores a wave issues per tile BEHIND the next tile's first direct-to-LDS loads (tiles inside the matrix only)
+template <int OUT>
+constexpr int late_stores() {
+  return OUT == kOutBf16 ? 16 : 32;
 }
 
 template <bool Q_KMAJOR, int OUT>
 __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[2 * kStageBytes];
 
-  int mt, nt, split;
-  if (!gemm_item(a, mt, nt, split)) return;
-  const int kt0 = split * a.ktiles_per_split;
-  int nk = a.ktiles - kt0;
-  if (nk > a.ktiles_per_split) nk = a.ktiles_per_split;
-  if (nk <= 0) return;
+#ifdef PRL_GEMM_STAMPS  // diagnostic build: where a workgroup's time goes (100 MHz clock), never in the product.
+  // Sums per phase in registers, written when the workgroup ends: a store to memory inside the loop would count
+  // among the operations the waits count, and one to LDS makes the compiler wait for every load in flight.
+  unsigned long long phase_sum[4] = {0, 0, 0, 0}, stamp_first = wall_clock64(), stamp_last = stamp_first;
+  const unsigned long long cycles_first = clock64();  // shader clock: its rate against the 100 MHz clock is the frequency
+  int stamped = 0;
+#define PRL_STAMP(i)                                  \
+  {                                                   \
+    const unsigned long long now = wall_clock64();    \
+    phase_sum[i] += now - stamp_last;                 \
+    stamp_last = now;                                 \
+  }
+#else
+#define PRL_STAMP(i)
+#endif
+  const int stride = (int)gridDim.x;
+  int item = (int)blockIdx.x, mt = 0, nt = 0, split = 0;
+  while (item < a.total_items && !gemm_item(a, item, mt, nt, split)) item += stride;
+  if (item >= a.total_items) return;
+  // Workgroups that start together and take the same time per item would all write their tiles back in the same
+  // couple of microseconds, 32 MB at once, and the next item's loads queue behind those stores in every compute
+  // unit.  Spread over one item's time, a few compute units write at any moment.
+  if (a.skew_ticks > 0) {
+    const unsigned rank = ((blockIdx.x >> 3) << 3 | (blockIdx.x & 7)) & 255u;
+    const unsigned long long t0 = wall_clock64(), wait = ((unsigned long long)a.skew_ticks * rank) >> 8;
+    while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+  }
 
   const int tid = (int)threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 2, wc = wid & 3;
-  const int m0 = mt * kBM, n0 = nt * kBN;
-
-  // Every compute unit gets the same work, so left alone they all reach their tile's write-back at the same
-  // moment, round after round, and the chip alternates between computing with idle memory and writing 32 MB at
-  // the memory's rate with idle matrix units.  The first workgroup of each compute unit therefore starts late by
-  // its own fraction of a tile's duration (bounded: at most stagger_ticks of the 100 MHz clock), which spreads
-  // the write-backs over the tile period for the rest of the launch; later workgroups inherit the offset.
-  if (a.stagger_ticks > 0 && blockIdx.x < 256u) {
-    const unsigned frac = ((unsigned)blockIdx.x * 157u) & 255u;  // a different 1/256th for each of the first 256
-    const unsigned long long until = wall_clock64() + (unsigned long long)((unsigned)a.stagger_ticks * frac >> 8);
-    while (wall_clock64() < until) __builtin_amdgcn_s_sleep(32);
-  }
 
   // ---- staging: per thread four 16-byte pieces of P and four of Q per K-tile
   // P (and a K-major Q): the quarter is [128 rows][64 k] with 128-byte rows; LDS slot (16 bytes) s = row * 8 + chunk
   // holds the row's chunk  chunk ^ ((row >> 1) & 7).
+  // MN-major Q: the quarter is [64 k][128 columns] with 256-byte rows; slot s = krow * 16 + chunk holds the row's
+  // chunk  chunk ^ (f(krow) << 1),  f(krow) = (krow & 3) | (((krow >> 3) & 1) << 2).
   const uint16_t* psrc[4];
   const uint16_t* qsrc[4];
-  {
+  int nk = 0;
+  auto set_sources = [&](int tid, int mt_, int nt_, int split_) {
+    const int m0 = mt_ * kBM, n0 = nt_ * kBN, kt0 = split_ * a.ktiles_per_split;
+    nk = a.ktiles - kt0;
+    if (nk > a.ktiles_per_split) nk = a.ktiles_per_split;
     const int chunk = (tid & 7) ^ ((tid >> 4) & 7);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {  // j = 2 * half + i
@@ -151,8 +181,6 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
         qsrc[j] = a.Q + (int64_t)row * a.ldq + (int64_t)kt0 * kBK + 8 * chunk;
       }
     } else {
-      // the quarter is [64 k][128 columns] with 256-byte rows; slot s = krow * 16 + chunk holds the row's chunk
-      // chunk ^ (f(krow) << 1),  f(krow) = (krow & 3) | (((krow >> 3) & 1) << 2)
       const int krow = tid >> 4;
       const int f = (krow & 3) | (((krow >> 3) & 1) << 2);
       const int ch = (tid & 15) ^ (f << 1);
@@ -163,7 +191,7 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
         qsrc[j] = a.Q + ((int64_t)kt0 * kBK + 32 * (j & 1) + krow) * a.ldq + col;
       }
     }
-  }
+  };
   const int64_t pstep = kBK, qstep = Q_KMAJOR ? (int64_t)kBK : (int64_t)kBK * a.ldq;
   // LDS destination of piece j of this wave inside a stage (the hardware adds 16 * lane)
   char* const wave_dst = smem + wid * 1024;
@@ -176,6 +204,17 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
   auto issue_q = [&](int stage, int j) {
     glds16(qsrc[j], wave_dst + stage * kStageBytes + 2 * kQuarterBytes + j * 8192);
     qsrc[j] += qstep;
+  };
+  // K-tile 0 of an item into stage 0, and the first two pieces of Q of its K-tile 1: 8 + 2 loads per thread
+  auto issue_prologue = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) issue_p(0, j);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) issue_q(0, j);
+    if (nk > 1) {
+      issue_q(1, 0);
+      issue_q(1, 1);
+    }
   };
 
   // ---- fragment addresses (bytes inside a stage)
@@ -208,11 +247,6 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
   };
 
   f32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
   bf16x8 af[4][2];     // the 64 rows of P this phase multiplies: row tiles 4 h .. 4 h + 3
   QFrag bx[2][2];      // Q columns 0 .. 31 of the wave (column tiles 0, 1)
   QFrag by[2][2];      // Q columns 32 .. 63 (column tiles 2, 3)
@@ -276,35 +310,116 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  // ---- prologue: K-tile 0 into stage 0, and the first two pieces of Q of K-tile 1
+  // ---- bf16 [M][N] write-back of the wave's 128 rows x 64 columns through a 16 KB LDS image of the wave's own
+  // (the eight images are the two stages), so that every store instruction writes 8 whole 128-byte rows instead of
+  // 16 pieces of 32 bytes.  Row r of the image keeps its 16-byte slot s at s ^ (r & 7): the 8-byte writes of 16
+  // rows and the 16-byte reads of 8 slots of two rows then spread over the banks.  `through_image` leaves the tile
+  // in v, 16 bytes per lane and store; `store_rows` writes v out.
+  // (These take the lane as an argument: given a value the compiler cannot see through, it does not hoist their
+  // address arithmetic, dozens of registers, out of the loop over work items and across the K loop.)
+  auto through_image = [&](int lane, u32x4 (&v)[16]) {
+    const int lr = lane & 15, lq = lane >> 4;
+    char* img = smem + wid * 16384;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) issue_p(0, j);
+    for (int rt = 0; rt < 8; ++rt) {
+      const int r = 16 * rt + lr;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) issue_q(0, j);
-  if (nk > 1) {
-    issue_q(1, 0);
-    issue_q(1, 1);
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  bar();
-  if (wid >= 4) bar();  // waves 4-7 run one section behind waves 0-3
+      for (int ct = 0; ct < 4; ++ct) {
+        const f32x4 x = acc[rt][ct];
+        const u32x2_t o = {pack_bf16(x[0], x[1]), pack_bf16(x[2], x[3])};
+        *reinterpret_cast<u32x2_t*>(img + r * 128 + (((2 * ct + (lq >> 1)) ^ (r & 7)) * 16) + 8 * (lq & 1)) = o;
+      }
+    }
+    const char* src = img + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) * 16);
+#pragma unroll
+    for (int it = 0; it < 16; ++it) v[it] = *reinterpret_cast<const u32x4*>(src + it * 1024);
+  };
+  auto store_rows = [&](int lane, int m0, int n0, bool inside, const u32x4 (&v)[16]) {
+    uint16_t* C = reinterpret_cast<uint16_t*>(a.C);
+    const int n = n0 + wc * 64 + 8 * (lane & 7);
+    const int mw = m0 + wr * 128 + (lane >> 3);
+    uint16_t* dst = C + (int64_t)mw * a.ldc + n;
+    if (inside) {
+#pragma unroll
+      for (int it = 0; it < 16; ++it)
+        __builtin_nontemporal_store(v[it], reinterpret_cast<u32x4*>(dst + (int64_t)(8 * it) * a.ldc));
+    } else {
+#pragma unroll
+      for (int it = 0; it < 16; ++it)
+        if (mw + 8 * it < a.M && n < a.N)
+          __builtin_nontemporal_store(v[it], reinterpret_cast<u32x4*>(dst + (int64_t)(8 * it) * a.ldc));
+    }
+  };
+  // the other output forms: straight from the accumulators (their tiles are a small share of these products)
+  auto store_direct = [&](int lane, int m0, int n0, int split_, bool inside) {
+    const int lr = lane & 15, lq = lane >> 4;
+    if (OUT == kOutBf16Transposed) {
+      uint16_t* C = reinterpret_cast<uint16_t*>(a.C);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const int n = n0 + wc * 64 + 16 * ct + lr;
+#pragma unroll
+        for (int rt = 0; rt < 8; ++rt) {
+          const int m = m0 + wr * 128 + 16 * rt + 4 * lq;
+          if (inside || (n < a.N && m < a.M)) {
+            const f32x4 x = acc[rt][ct];
+            const u32x2_t o = {pack_bf16(x[0], x[1]), pack_bf16(x[2], x[3])};
+            *reinterpret_cast<u32x2_t*>(C + (int64_t)n * a.ldc + m) = o;
+          }
+        }
+      }
+    } else {
+      float* C = reinterpret_cast<float*>(a.C) + (int64_t)split_ * a.slab_stride;
+#pragma unroll
+      for (int rt = 0; rt < 8; ++rt) {
+        const int m = m0 + wr * 128 + 16 * rt + lr;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          const int n = n0 + wc * 64 + 16 * ct + 4 * lq;
+          if (inside || (m < a.M && n < a.N)) *reinterpret_cast<f32x4*>(C + (int64_t)m * a.ldc + n) = acc[rt][ct];
+        }
+      }
+    }
+  };
 
-  // One K-tile u out of stage S: four phases, each a load section, a barrier, an MFMA section, a barrier.
-  //   phase 0: reads a0 (rows 0-63 of the wave) and b0 (columns 0-31);   multiplies (a0, b0)
-  //   phase 1: reads b1;                                                 multiplies (a0, b1)
-  //   phase 2: reads a1;                                                 multiplies (a1, b1)
-  //   phase 3: reads nothing;                                            multiplies (a1, b0)
-  // Every load section also issues two of the eight direct-to-LDS pieces a thread contributes per K-tile, as early
-  // as the slot they overwrite is dead: Q of tile u+2 goes into THIS stage from phase 3 on (its Q slots were last
-  // read in phase 1), the rest of Q and then P of tile u+1 into the other stage in phases 0-2.  A slot counts as
-  // dead once every wave has waited for its last reads of it and a barrier has followed.  Pieces are waited for
-  // with counted waits (a wave's vector-memory operations retire in issue order), always before a barrier that
-  // every reader passes before its first read:
-  //   end of phase 3's load section: Q of u+1 and the a0 pieces of P of u+1 (read from phase 0 of u+1 on); what may
-  //     stay in flight: the a1 pieces of u+1 and the two pieces of Q of u+2 just issued;
-  //   end of phase 1's load section: the a1 pieces of P of u (read in phase 2); in flight: all six younger pieces.
+  set_sources(tid, mt, nt, split);
+  issue_prologue();
+  int behind = 0;  // stores this wave issued behind the prologue loads now in flight (0 or late_stores<OUT>())
+
+  for (;;) {
+    PRL_STAMP(0)
+    const int m0 = mt * kBM, n0 = nt * kBN, my_split = split;
+    const bool inside = m0 + kBM <= a.M && n0 + kBN <= a.N;
+    // K-tile 0 has landed: everything but the two pieces of K-tile 1 and the stores issued behind them
+    if (behind) {
+      if (nk > 1) wait_vmcnt<2 + late_stores<OUT>()>(); else wait_vmcnt<late_stores<OUT>()>();
+    } else {
+      if (nk > 1) wait_vmcnt<2>(); else wait_vmcnt<0>();
+    }
+    bar();
+    PRL_STAMP(1)
+    if (wid >= 4) bar();  // waves 4-7 run one section behind waves 0-3
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // One K-tile u out of stage S: four phases, each a load section, a barrier, an MFMA section, a barrier.
+    //   phase 0: reads a0 (rows 0-63 of the wave) and b0 (columns 0-31);   multiplies (a0, b0)
+    //   phase 1: reads b1;                                                 multiplies (a0, b1)
+    //   phase 2: reads a1;                                                 multiplies (a1, b1)
+    //   phase 3: reads nothing;                                            multiplies (a1, b0)
+    // Every load section also issues two of the eight direct-to-LDS pieces a thread contributes per K-tile, as
+    // early as the slot they overwrite is dead: Q of tile u+2 goes into THIS stage from phase 3 on (its Q slots
+    // were last read in phase 1), the rest of Q and then P of tile u+1 into the other stage in phases 0-2.  A slot
+    // counts as dead once every wave has waited for its last reads of it and a barrier has followed.  Pieces are
+    // waited for with counted waits (a wave's vector-memory operations retire in issue order), always before a
+    // barrier that every reader passes before its first read:
+    //   end of phase 3's load section: Q of u+1 and the a0 pieces of P of u+1 (read from phase 0 of u+1 on); what
+    //     may stay in flight: the a1 pieces of u+1 and the two pieces of Q of u+2 just issued;
+    //   end of phase 1's load section: the a1 pieces of P of u (read in phase 2); in flight: all six younger
+    //     pieces.  Not in K-tile 0, whose pieces the wait in front of the loop has covered (and where stores of the
+    //     last tile may still be in flight, which a counted wait would wait for as well).
 #define PRL_GEMM_TILE(S)                                                            \
   {                                                                                 \
     const bool n1 = u + 1 < nk, n2 = u + 2 < nk;                                    \
@@ -317,8 +432,7 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
     bar();                                                                          \
     if (n1) { issue_p((S) ^ 1, 0); issue_p((S) ^ 1, 2); }                           \
     load_b((S), 1, by);                                                             \
-    if (n1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                        \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           \
+    if (n1) wait_vmcnt<6>(); else wait_vmcnt<0>();                                  \
     bar();                                                                          \
     wait_tr_reads(by);                                                              \
     mma(0, 1, by);                                                                  \
@@ -331,96 +445,97 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
     if (n2) {                                                                       \
       issue_q((S), 0);                                                              \
       issue_q((S), 1);                                                              \
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                              \
+      wait_vmcnt<4>();                                                              \
     } else if (n1) {                                                                \
-      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                              \
+      wait_vmcnt<2>();                                                              \
     }                                                                               \
     bar();                                                                          \
     mma(1, 0, bx);                                                                  \
     bar();                                                                          \
   }
 
-  for (int u = 0; u < nk; u += 2) {
-    PRL_GEMM_TILE(0)
-    ++u;
-    if (u >= nk) break;
-    PRL_GEMM_TILE(1)
-    --u;
-  }
+    {
+      int u = 0;
+      for (; u + 1 < nk; ++u) {
+        PRL_GEMM_TILE(0)
+        ++u;
+        PRL_GEMM_TILE(1)
+      }
+      if (u < nk) PRL_GEMM_TILE(0)
+    }
 #undef PRL_GEMM_TILE
-  if (wid < 4) bar();
+    if (wid < 4) bar();
+    PRL_STAMP(2)
 
-  // ---- epilogue: every lane holds, per accumulator tile, 4 consecutive elements along the contiguous index
-  const int lr = lane & 15, lq = lane >> 4;
-#ifdef PRL_GEMM_SKIP_STORE  // timing experiment only: the tile is computed and (almost surely) not stored
-  if (acc[0][0][0] != 12345.678f) return;
-#endif
-  if (OUT == kOutBf16Transposed) {
-    uint16_t* C = reinterpret_cast<uint16_t*>(a.C);
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-      const int n = n0 + wc * 64 + 16 * ct + lr;
-#pragma unroll
-      for (int rt = 0; rt < 8; ++rt) {
-        const int m = m0 + wr * 128 + 16 * rt + 4 * lq;
-        if (n < a.N && m < a.M) {
-          const f32x4 v = acc[rt][ct];
-          u32x2_t o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
-          *reinterpret_cast<u32x2_t*>(C + (int64_t)n * a.ldc + m) = o;
+    // ---- the item's write-back, with the next item's first loads already on their way
+    int nitem = item + stride, nmt = 0, nnt = 0, nsp = 0;
+    while (nitem < a.total_items && !gemm_item(a, nitem, nmt, nnt, nsp)) nitem += stride;
+    const bool more = nitem < a.total_items;
+    int tid_e = tid;  // the thread id again, opaque (see through_image)
+    asm volatile("" : "+v"(tid_e));
+    const int lane_e = tid_e & 63;
+    if (OUT == kOutBf16) {
+      u32x4 late[16];
+      through_image(lane_e, late);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      bar();  // every wave has read its image back: the stages may be overwritten
+      if (inside) {
+        if (more) {
+          set_sources(tid_e, nmt, nnt, nsp);
+          issue_prologue();
         }
+#ifdef PRL_GEMM_SKIP_STORE  // diagnostic build: what the kernel takes without its write-back (results are not written)
+        if (a.M < 0) store_rows(lane_e, m0, n0, true, late);
+        behind = 0;
+#else
+        store_rows(lane_e, m0, n0, true, late);
+        behind = late_stores<OUT>();
+#endif
+      } else {  // a tile on the matrix's edge: how many stores a wave issues varies, so they go first
+        store_rows(lane_e, m0, n0, false, late);
+        if (more) {
+          set_sources(tid_e, nmt, nnt, nsp);
+          issue_prologue();
+        }
+        behind = 0;
       }
-    }
-  } else if (OUT == kOutF32Slab) {
-    float* C = reinterpret_cast<float*>(a.C) + (int64_t)split * a.slab_stride;
-#pragma unroll
-    for (int rt = 0; rt < 8; ++rt) {
-      const int m = m0 + wr * 128 + 16 * rt + lr;
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
-        const int n = n0 + wc * 64 + 16 * ct + 4 * lq;
-        if (m < a.M && n < a.N) *reinterpret_cast<f32x4*>(C + (int64_t)m * a.ldc + n) = acc[rt][ct];
-      }
-    }
-  } else {
-    // bf16 [M][N]: the wave's 128 x 64 elements go through a 16 KB LDS image of its own (the stages are dead
-    // behind the last barrier) so that every store instruction writes 8 whole 128-byte rows, instead of 16
-    // pieces of 32 bytes: a compute unit retires stores at a few cycles per distinct line touched.  Row r of the
-    // image keeps its 16-byte slot s at s ^ (r & 7): the 8-byte writes of 16 rows and the 16-byte reads of 8 slots
-    // of two rows then spread over the banks.
-    char* img = smem + wid * 16384;
-#pragma unroll
-    for (int rt = 0; rt < 8; ++rt) {
-      const int r = 16 * rt + lr;
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
-        const f32x4 v = acc[rt][ct];
-        const u32x2_t o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
-        *reinterpret_cast<u32x2_t*>(img + r * 128 + (((2 * ct + (lq >> 1)) ^ (r & 7)) * 16) + 8 * (lq & 1)) = o;
-      }
-    }
-    uint16_t* C = reinterpret_cast<uint16_t*>(a.C);
-    const int n = n0 + wc * 64 + 8 * (lane & 7);
-    const int mw = m0 + wr * 128 + (lane >> 3);
-    const char* src = img + (lane >> 3) * 128;
-    const int slot = lane & 7, rsw = (lane >> 3) & 7;  // row r = 8 it + (lane >> 3): r & 7 does not depend on it
-    uint16_t* dst = C + (int64_t)mw * a.ldc + n;
-    if (m0 + kBM <= a.M && n0 + kBN <= a.N) {
-      // tile inside the matrix: all reads first, then all stores, nothing conditional
-      u32x4 v[16];
-#pragma unroll
-      for (int it = 0; it < 16; ++it) v[it] = *reinterpret_cast<const u32x4*>(src + it * 1024 + ((slot ^ rsw) * 16));
-#pragma unroll
-      for (int it = 0; it < 16; ++it)
-        __builtin_nontemporal_store(v[it], reinterpret_cast<u32x4*>(dst + (int64_t)(8 * it) * a.ldc));
     } else {
-#pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(src + it * 1024 + ((slot ^ rsw) * 16));
-        if (mw + 8 * it < a.M && n < a.N)
-          __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst + (int64_t)(8 * it) * a.ldc));
+      if (inside) {
+        if (more) {
+          set_sources(tid_e, nmt, nnt, nsp);
+          issue_prologue();
+        }
+        store_direct(lane_e, m0, n0, my_split, true);
+        behind = late_stores<OUT>();
+      } else {
+        store_direct(lane_e, m0, n0, my_split, false);
+        if (more) {
+          set_sources(tid_e, nmt, nnt, nsp);
+          issue_prologue();
+        }
+        behind = 0;
       }
     }
+    PRL_STAMP(3)
+#ifdef PRL_GEMM_STAMPS
+    ++stamped;
+#endif
+    if (!more) break;
+    item = nitem;
+    mt = nmt;
+    nt = nnt;
+    split = nsp;
   }
+#ifdef PRL_GEMM_STAMPS
+  if (a.stamps && threadIdx.x == 0) {
+    unsigned long long* out = a.stamps + (size_t)blockIdx.x * 8;
+    for (int i = 0; i < 4; ++i) out[i] = phase_sum[i];
+    out[4] = (unsigned long long)stamped;
+    out[5] = stamp_first;
+    out[6] = stamp_last;
+    out[7] = clock64() - cycles_first;
+  }
+#endif
 }
 
 // out[c][r] = in[r][c] for a bf16 [rows][cols] matrix: 64 x 64 blocks through LDS, 16-byte loads and stores.
@@ -452,12 +567,6 @@ __global__ void __launch_bounds__(256) k_transpose_bf16(const uint16_t* __restri
   }
 }
 
-static int forward_stagger(int ktiles) {
-  const char* e = getenv("PRL_LM_HEAD_STAGGER");  // ticks of 10 ns per K-tile; 0 switches the spreading off
-  const int per_tile = e ? atoi(e) : 150;
-  return per_tile <= 0 ? 0 : per_tile * ktiles;
-}
-
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 static GemmArgs make_args(const void* P, int64_t ldp, const void* Q, int64_t ldq, void* C, int64_t ldc, int64_t M,
@@ -477,15 +586,31 @@ static GemmArgs make_args(const void* P, int64_t ldp, const void* Q, int64_t ldq
   a.nsplit = (a.ktiles + a.ktiles_per_split - 1) / a.ktiles_per_split;  // no split without a K-tile
   a.mtiles = (int)((M + kBM - 1) / kBM);
   a.ntiles = (int)((N + kBN - 1) / kBN);
-  a.super_m = (a.mtiles + kSuperM - 1) / kSuperM;
-  a.super_n = (a.ntiles + kSuperN - 1) / kSuperN;
-  a.stagger_ticks = 0;
+  // the super-tile shape that pads least (8 x 4 tiles, 4 x 8, 2 x 16 or 1 x 32); the taller one on a tie
+  int64_t best = -1;
+  for (int lg = 3; lg >= 0; --lg) {
+    const int dm = 1 << lg, dn = 32 >> lg;
+    const int64_t padded = (int64_t)((a.mtiles + dm - 1) / dm) * ((a.ntiles + dn - 1) / dn);
+    if (best < 0 || padded < best) {
+      best = padded;
+      a.super_log2 = lg;
+    }
+  }
+  a.super_m = (a.mtiles + (1 << a.super_log2) - 1) >> a.super_log2;
+  a.super_n = (a.ntiles + (32 >> a.super_log2) - 1) / (32 >> a.super_log2);
+  a.total_items = 256 * ((a.super_m * a.super_n * a.nsplit + 7) / 8);
+  a.stamps = nullptr;
+  // an item takes about 1.5 us per K-tile and 4 us around the K loop; no skew where a workgroup has few items
+  a.skew_ticks = 0;
+  if (a.total_items >= 256 * 8) {
+    int percent = 100;
+    if (const char* e = getenv("PRL_LM_HEAD_SKEW")) percent = atoi(e);
+    a.skew_ticks = (a.ktiles_per_split * 150 + 400) * percent / 100;
+  }
   return a;
 }
-static unsigned gemm_grid(const GemmArgs& a) {
-  const int supers = a.super_m * a.super_n * a.nsplit;
-  return 8u * 32u * (unsigned)((supers + 7) / 8);
-}
+// one workgroup per compute unit of the chip (the kernel walks over its work items); fewer when there is less work
+static unsigned gemm_grid(const GemmArgs& a) { return 256u; }
 
 // K splits for the input-gradient product: few tiles of C, a very long K.  The chip works the tiles off in rounds
 // of one per compute unit, so the time goes with ceil(tiles * splits / 256) / splits; the smallest split count
@@ -509,6 +634,11 @@ static int dx_splits(int64_t T, int64_t H, int64_t V) {
 }  // namespace prl
 
 using namespace prl;
+
+#ifdef PRL_GEMM_STAMPS
+static unsigned long long* g_stamps = nullptr;
+extern "C" void prl_lm_head_set_stamps(void* p) { g_stamps = (unsigned long long*)p; }
+#endif
 
 extern "C" int prl_lm_head_supported(int dtype, int64_t T, int64_t H, int64_t V) {
   return dtype == PRL_BF16 && T >= 1 && H >= kBK && V >= 8 && H % kBK == 0 && V % kBK == 0 && T % kBK == 0 &&
@@ -534,8 +664,9 @@ extern "C" int prl_lm_head_fwd(const void* hidden, int64_t hidden_stride, const 
                   logits_stride >= V && logits_stride % 8 == 0,
               "prl_lm_head_fwd: pointers must be 16-byte aligned and row strides multiples of 8 elements");
   GemmArgs a = make_args(hidden, hidden_stride, weight, weight_stride, logits, logits_stride, T, V, H, 1);
-  // write-backs are a sixth of this product's time at H = 1024: spread them (k_lm_gemm); a K-tile takes ~1.5 us
-  if ((int64_t)a.mtiles * a.ntiles >= 1024) a.stagger_ticks = forward_stagger(a.ktiles);
+#ifdef PRL_GEMM_STAMPS
+  a.stamps = g_stamps;
+#endif
   hipLaunchKernelGGL((k_lm_gemm<true, kOutBf16>), dim3(gemm_grid(a)), dim3(kGemmThreads), 0, (hipStream_t)stream, a);
   PRL_CHECK_LAUNCH("k_lm_gemm (forward)");
   return PRL_OK;
