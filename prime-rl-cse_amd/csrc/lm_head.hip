@@ -50,7 +50,6 @@ struct GemmArgs {
   int super_log2;        // a super-tile is (1 << super_log2) x (32 >> super_log2) tiles of C
   int super_m, super_n;  // super-tiles along M and N
   int total_items;       // 256 * ceil(super_m * super_n * nsplit / 8): work items, valid or not
-  int skew_ticks;        // workgroup b starts (b's rank among 256) / 256 * skew_ticks of the 100 MHz clock late
   unsigned long long* stamps;  // diagnostic builds only (PRL_GEMM_STAMPS): 8 clock readings per work item, or NULL
 };
 
@@ -141,15 +140,6 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
   int item = (int)blockIdx.x, mt = 0, nt = 0, split = 0;
   while (item < a.total_items && !gemm_item(a, item, mt, nt, split)) item += stride;
   if (item >= a.total_items) return;
-  // Workgroups that start together and take the same time per item would all write their tiles back in the same
-  // couple of microseconds, 32 MB at once, and the next item's loads queue behind those stores in every compute
-  // unit.  Spread over one item's time, a few compute units write at any moment.
-  if (a.skew_ticks > 0) {
-    const unsigned rank = ((blockIdx.x >> 3) << 3 | (blockIdx.x & 7)) & 255u;
-    const unsigned long long t0 = wall_clock64(), wait = ((unsigned long long)a.skew_ticks * rank) >> 8;
-    while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(8);
-  }
-
   const int tid = (int)threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 2, wc = wid & 3;
@@ -600,13 +590,6 @@ static GemmArgs make_args(const void* P, int64_t ldp, const void* Q, int64_t ldq
   a.super_n = (a.ntiles + (32 >> a.super_log2) - 1) / (32 >> a.super_log2);
   a.total_items = 256 * ((a.super_m * a.super_n * a.nsplit + 7) / 8);
   a.stamps = nullptr;
-  // an item takes about 1.5 us per K-tile and 4 us around the K loop; no skew where a workgroup has few items
-  a.skew_ticks = 0;
-  if (a.total_items >= 256 * 8) {
-    int percent = 100;
-    if (const char* e = getenv("PRL_LM_HEAD_SKEW")) percent = atoi(e);
-    a.skew_ticks = (a.ktiles_per_split * 150 + 400) * percent / 100;
-  }
   return a;
 }
 // one workgroup per compute unit of the chip (the kernel walks over its work items); fewer when there is less work

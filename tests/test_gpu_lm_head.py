@@ -19,9 +19,11 @@ def _ints(shape, lo, hi, gen, dev):
 
 
 # ragged edges on every side: rows and columns that are not multiples of the 256-wide tile, one K-tile, odd and
-# even numbers of K-tiles, a K split over workgroups with an empty last split (1024 x 256 x 4160)
+# even numbers of K-tiles, a K split over workgroups with an empty last split (1024 x 256 x 4160), workgroups that
+# walk several tiles with edge tiles among them (1088 x 128 x 16448) and several fp32 slabs of different K splits
+# (5120 x 3840 x 2048)
 SHAPES = [(256, 64, 256), (512, 128, 1088), (192, 192, 832), (1024, 256, 4160), (2048, 1024, 2560), (64, 64, 64),
-          (320, 448, 1984)]
+          (320, 448, 1984), (1088, 128, 16448), (5120, 3840, 2048)]
 
 
 @pytest.mark.parametrize("t,h,v", SHAPES)
@@ -87,6 +89,7 @@ def test_autograd_function_matches_torch_linear(monkeypatch):
 def test_plan_follows_the_switches(monkeypatch):
     monkeypatch.delenv("PRL_LM_HEAD", raising=False)
     assert L.plan(2048, 1024, 151936) == (False, True, True)
+    assert L.plan(2048, 5120, 152064) == (True, True, True)  # the forward product from hidden size 4096 on
     assert L.plan(100, 1024, 151936) == (False, False, False)  # not a multiple of 64: the library's
     monkeypatch.setenv("PRL_LM_HEAD", "hip")
     assert L.plan(2048, 1024, 151936) == (True, True, True)

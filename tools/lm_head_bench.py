@@ -31,7 +31,8 @@ def ints(shape, lo, hi, gen, dev):
 def exact_cases(dev):
     gen = torch.Generator(device=dev).manual_seed(1)
     bad = 0
-    for t, h, v in [(256, 64, 256), (512, 128, 1088), (192, 192, 832), (1024, 256, 4160), (2048, 1024, 2560)]:
+    for t, h, v in [(256, 64, 256), (512, 128, 1088), (192, 192, 832), (1024, 256, 4160), (2048, 1024, 2560),
+                    (1088, 128, 16448), (5120, 3840, 2048)]:
         x = ints((t, h), -2, 2, gen, dev)
         w = ints((v, h), -2, 2, gen, dev)
         g = ints((t, v), -1, 1, gen, dev)
