@@ -38,7 +38,7 @@ def build() -> None:
     subprocess.run(["make", "-C", str(CSRC), "-j8"], check=True)
     TUNE.mkdir(parents=True, exist_ok=True)
     others = [str(LIB / "obj" / f"{n}.o") for n in ("capi", "logprob", "segments", "loss", "advantage", "stats", "policy",
-                                                      "norm", "accum", "attn_short", "attn_long", "optim")]
+                                                      "norm", "accum", "attn_short", "attn_long", "optim", "lm_head")]
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Xclang", "-target-feature", "-Xclang",
              "-packed-fp32-ops", f"-I{REPO / 'include'}", f"-I{CSRC}"]
     for tag, defs in VARIANTS.items():
