@@ -50,6 +50,7 @@ struct GemmArgs {
   int super_log2;        // a super-tile is (1 << super_log2) x (32 >> super_log2) tiles of C
   int super_m, super_n;  // super-tiles along M and N
   int total_items;       // 256 * ceil(super_m * super_n * nsplit / 8): work items, valid or not
+  int cached_stores;     // bf16 tiles inside the matrix are stored with cacheable instead of non-temporal stores
   unsigned long long* stamps;  // diagnostic builds only (PRL_GEMM_STAMPS): 8 clock readings per work item, or NULL
 };
 
@@ -324,15 +325,23 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
 #pragma unroll
     for (int it = 0; it < 16; ++it) v[it] = *reinterpret_cast<const u32x4*>(src + it * 1024);
   };
+  // Cacheable stores where the K loop is short (`a.cached_stores`: the logits of a narrow model, +2 % at H = 1024:
+  // the write-backs of 256 units drain through the caches instead of meeting at the memory), non-temporal ones
+  // otherwise (at H = 3584 and 5120 cacheable stores cost 6-7 %: the output lines push operand panels out).
   auto store_rows = [&](int lane, int m0, int n0, bool inside, const u32x4 (&v)[16]) {
     uint16_t* C = reinterpret_cast<uint16_t*>(a.C);
     const int n = n0 + wc * 64 + 8 * (lane & 7);
     const int mw = m0 + wr * 128 + (lane >> 3);
     uint16_t* dst = C + (int64_t)mw * a.ldc + n;
     if (inside) {
+      if (a.cached_stores) {
 #pragma unroll
-      for (int it = 0; it < 16; ++it)
-        __builtin_nontemporal_store(v[it], reinterpret_cast<u32x4*>(dst + (int64_t)(8 * it) * a.ldc));
+        for (int it = 0; it < 16; ++it) *reinterpret_cast<u32x4*>(dst + (int64_t)(8 * it) * a.ldc) = v[it];
+      } else {
+#pragma unroll
+        for (int it = 0; it < 16; ++it)
+          __builtin_nontemporal_store(v[it], reinterpret_cast<u32x4*>(dst + (int64_t)(8 * it) * a.ldc));
+      }
     } else {
 #pragma unroll
       for (int it = 0; it < 16; ++it)
@@ -590,6 +599,7 @@ static GemmArgs make_args(const void* P, int64_t ldp, const void* Q, int64_t ldq
   a.super_n = (a.ntiles + (32 >> a.super_log2) - 1) / (32 >> a.super_log2);
   a.total_items = 256 * ((a.super_m * a.super_n * a.nsplit + 7) / 8);
   a.stamps = nullptr;
+  a.cached_stores = a.ktiles_per_split <= 16;  // (only the forward product at H <= 1024 stores bf16 tiles that often)
   return a;
 }
 // one workgroup per compute unit of the chip (the kernel walks over its work items); fewer when there is less work
