@@ -196,12 +196,14 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
     glds16(qsrc[j], wave_dst + stage * kStageBytes + 2 * kQuarterBytes + j * 8192);
     qsrc[j] += qstep;
   };
-  // K-tile 0 of an item into stage 0, and the first two pieces of Q of its K-tile 1: 8 + 2 loads per thread
-  auto issue_prologue = [&]() {
+  // K-tile 0 of an item into stage 0 (8 loads per thread), and the first two pieces of Q of its K-tile 1 into stage 1
+  auto issue_tile0 = [&]() {
 #pragma unroll
     for (int j = 0; j < 4; ++j) issue_p(0, j);
 #pragma unroll
     for (int j = 0; j < 4; ++j) issue_q(0, j);
+  };
+  auto issue_q1 = [&]() {
     if (nk > 1) {
       issue_q(1, 0);
       issue_q(1, 1);
@@ -301,50 +303,52 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  // ---- bf16 [M][N] write-back of the wave's 128 rows x 64 columns through a 16 KB LDS image of the wave's own
-  // (the eight images are the two stages), so that every store instruction writes 8 whole 128-byte rows instead of
-  // 16 pieces of 32 bytes.  Row r of the image keeps its 16-byte slot s at s ^ (r & 7): the 8-byte writes of 16
-  // rows and the 16-byte reads of 8 slots of two rows then spread over the banks.  `through_image` leaves the tile
-  // in v, 16 bytes per lane and store; `store_rows` writes v out.
+  // ---- bf16 [M][N] write-back of the wave's 128 rows x 64 columns, 64 rows at a time through an 8 KB LDS image of
+  // the wave's own in stage 1 (stage 0 is already receiving the next item's first K-tile), so that every store
+  // instruction writes 8 whole 128-byte rows instead of 16 pieces of 32 bytes.  Row r of the image keeps its 16-byte
+  // slot s at s ^ (r & 7): the 8-byte writes of 16 rows and the 16-byte reads of 8 slots of two rows then spread
+  // over the banks.  `through_image` leaves half h of the tile in v, 16 bytes per lane and store; `store_rows`
+  // writes v out.  The image is the wave's own and the LDS works a wave's operations in order, so the second half
+  // needs no barrier behind the first.
   // (These take the lane as an argument: given a value the compiler cannot see through, it does not hoist their
   // address arithmetic, dozens of registers, out of the loop over work items and across the K loop.)
-  auto through_image = [&](int lane, u32x4 (&v)[16]) {
+  auto through_image = [&](int lane, int h, int stage, u32x4 (&v)[8]) {
     const int lr = lane & 15, lq = lane >> 4;
-    char* img = smem + wid * 16384;
+    char* img = smem + stage * kStageBytes + wid * 8192;
 #pragma unroll
-    for (int rt = 0; rt < 8; ++rt) {
-      const int r = 16 * rt + lr;
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int r = 16 * r4 + lr;
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) {
-        const f32x4 x = acc[rt][ct];
+        const f32x4 x = acc[4 * h + r4][ct];
         const u32x2_t o = {pack_bf16(x[0], x[1]), pack_bf16(x[2], x[3])};
         *reinterpret_cast<u32x2_t*>(img + r * 128 + (((2 * ct + (lq >> 1)) ^ (r & 7)) * 16) + 8 * (lq & 1)) = o;
       }
     }
     const char* src = img + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) * 16);
 #pragma unroll
-    for (int it = 0; it < 16; ++it) v[it] = *reinterpret_cast<const u32x4*>(src + it * 1024);
+    for (int it = 0; it < 8; ++it) v[it] = *reinterpret_cast<const u32x4*>(src + it * 1024);
   };
   // Cacheable stores where the K loop is short (`a.cached_stores`: the logits of a narrow model, +2 % at H = 1024:
   // the write-backs of 256 units drain through the caches instead of meeting at the memory), non-temporal ones
   // otherwise (at H = 3584 and 5120 cacheable stores cost 6-7 %: the output lines push operand panels out).
-  auto store_rows = [&](int lane, int m0, int n0, bool inside, const u32x4 (&v)[16]) {
+  auto store_rows = [&](int lane, int m0, int n0, int h, bool inside, const u32x4 (&v)[8]) {
     uint16_t* C = reinterpret_cast<uint16_t*>(a.C);
     const int n = n0 + wc * 64 + 8 * (lane & 7);
-    const int mw = m0 + wr * 128 + (lane >> 3);
+    const int mw = m0 + wr * 128 + 64 * h + (lane >> 3);
     uint16_t* dst = C + (int64_t)mw * a.ldc + n;
     if (inside) {
       if (a.cached_stores) {
 #pragma unroll
-        for (int it = 0; it < 16; ++it) *reinterpret_cast<u32x4*>(dst + (int64_t)(8 * it) * a.ldc) = v[it];
+        for (int it = 0; it < 8; ++it) *reinterpret_cast<u32x4*>(dst + (int64_t)(8 * it) * a.ldc) = v[it];
       } else {
 #pragma unroll
-        for (int it = 0; it < 16; ++it)
+        for (int it = 0; it < 8; ++it)
           __builtin_nontemporal_store(v[it], reinterpret_cast<u32x4*>(dst + (int64_t)(8 * it) * a.ldc));
       }
     } else {
 #pragma unroll
-      for (int it = 0; it < 16; ++it)
+      for (int it = 0; it < 8; ++it)
         if (mw + 8 * it < a.M && n < a.N)
           __builtin_nontemporal_store(v[it], reinterpret_cast<u32x4*>(dst + (int64_t)(8 * it) * a.ldc));
     }
@@ -382,14 +386,15 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
   };
 
   set_sources(tid, mt, nt, split);
-  issue_prologue();
-  int behind = 0;  // stores this wave issued behind the prologue loads now in flight (0 or late_stores<OUT>())
+  issue_tile0();
+  issue_q1();
+  int behind = 0;  // stores this wave issued behind the loads of K-tile 0 now in flight (0 or late_stores<OUT>())
 
   for (;;) {
     PRL_STAMP(0)
     const int m0 = mt * kBM, n0 = nt * kBN, my_split = split;
     const bool inside = m0 + kBM <= a.M && n0 + kBN <= a.N;
-    // K-tile 0 has landed: everything but the two pieces of K-tile 1 and the stores issued behind them
+    // K-tile 0 has landed: everything but the two pieces of K-tile 1 and the stores issued behind K-tile 0's loads
     if (behind) {
       if (nk > 1) wait_vmcnt<2 + late_stores<OUT>()>(); else wait_vmcnt<late_stores<OUT>()>();
     } else {
@@ -474,35 +479,34 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
     asm volatile("" : "+v"(tid_e));
     const int lane_e = tid_e & 63;
     if (OUT == kOutBf16) {
-      u32x4 late[16];
-      through_image(lane_e, late);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      bar();  // every wave has read its image back: the stages may be overwritten
-      if (inside) {
-        if (more) {
-          set_sources(tid_e, nmt, nnt, nsp);
-          issue_prologue();
-        }
-#ifdef PRL_GEMM_SKIP_STORE  // diagnostic build: what the kernel takes without its write-back (results are not written)
-        if (a.M < 0) store_rows(lane_e, m0, n0, true, late);
-        behind = 0;
-#else
-        store_rows(lane_e, m0, n0, true, late);
-        behind = late_stores<OUT>();
-#endif
-      } else {  // a tile on the matrix's edge: how many stores a wave issues varies, so they go first
-        store_rows(lane_e, m0, n0, false, late);
-        if (more) {
-          set_sources(tid_e, nmt, nnt, nsp);
-          issue_prologue();
-        }
-        behind = 0;
+      // The next item's first K-tile goes into stage 0 at once (every wave has passed its last reads of both
+      // stages), a write-back's time ahead of its first use; the tile leaves through stage 1 meanwhile.
+      if (more) {
+        set_sources(tid_e, nmt, nnt, nsp);
+        issue_tile0();
       }
+      u32x4 half[8];
+#ifdef PRL_GEMM_SKIP_STORE  // diagnostic build: what the kernel takes without its write-back (results are not written)
+      const bool really = a.M < 0;
+#else
+      const bool really = true;
+#endif
+      through_image(lane_e, 0, 1, half);
+      if (really) store_rows(lane_e, m0, n0, 0, inside, half);
+      through_image(lane_e, 1, 1, half);
+      if (really) store_rows(lane_e, m0, n0, 1, inside, half);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      bar();  // every wave has read its image back: stage 1 may be overwritten
+      if (more) issue_q1();
+      // behind the eight loads of the next K-tile 0: 16 stores (a tile inside the matrix; otherwise a number the
+      // wait cannot know, and it waits for all of them) and the two loads just issued
+      behind = inside && really ? late_stores<OUT>() : 0;
     } else {
       if (inside) {
         if (more) {
           set_sources(tid_e, nmt, nnt, nsp);
-          issue_prologue();
+          issue_tile0();
+          issue_q1();
         }
         store_direct(lane_e, m0, n0, my_split, true);
         behind = late_stores<OUT>();
@@ -510,7 +514,8 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
         store_direct(lane_e, m0, n0, my_split, false);
         if (more) {
           set_sources(tid_e, nmt, nnt, nsp);
-          issue_prologue();
+          issue_tile0();
+          issue_q1();
         }
         behind = 0;
       }

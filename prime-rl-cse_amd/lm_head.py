@@ -98,14 +98,14 @@ def plan(t: int, h: int, v: int) -> tuple[bool, bool, bool]:
 
     Default (`PRL_LM_HEAD=auto`): the two backward products, where the kernels are ahead of the library at every
     recipe shape measured (input gradient 1.05-2.15x, weight gradient 1.15-1.30x; `tools/lm_head_shapes.sh`), and
-    the forward product only for hidden sizes from 4096 on (1.07x at 5120; 0.5-4.5 % behind the library at 1024 to
-    3584, where the write-back of the logits is a larger share of a tile's time).  `PRL_LM_HEAD=hip` / `lib` take all
-    three from one side; `PRL_LM_HEAD_FWD`, `PRL_LM_HEAD_DX`, `PRL_LM_HEAD_DW` = 0 / 1 set one product."""
+    the forward product except for hidden sizes between 2048 and 4096 (1.03-1.06x at 1024, level at 2048, 1.05x at
+    5120; 1-2 % behind the library at 3584).  `PRL_LM_HEAD=hip` / `lib` take all three from one side;
+    `PRL_LM_HEAD_FWD`, `PRL_LM_HEAD_DX`, `PRL_LM_HEAD_DW` = 0 / 1 set one product."""
     mode = os.environ.get("PRL_LM_HEAD", "auto")
     if mode not in ("auto", "hip", "lib"):
         raise RuntimeError(f"PRL_LM_HEAD must be auto, hip or lib, got {mode!r}")
     takes = bool(_capi.load().prl_lm_head_supported(_capi.PRL_BF16, t, h, v))
-    ours = {"auto": (h >= 4096, True, True), "hip": (True, True, True), "lib": (False, False, False)}[mode]
+    ours = {"auto": (h <= 2048 or h >= 4096, True, True), "hip": (True, True, True), "lib": (False, False, False)}[mode]
     if not takes and mode == "auto":
         ours = (False, False, False)
     out = []

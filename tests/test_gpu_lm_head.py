@@ -88,8 +88,9 @@ def test_autograd_function_matches_torch_linear(monkeypatch):
 
 def test_plan_follows_the_switches(monkeypatch):
     monkeypatch.delenv("PRL_LM_HEAD", raising=False)
-    assert L.plan(2048, 1024, 151936) == (False, True, True)
-    assert L.plan(2048, 5120, 152064) == (True, True, True)  # the forward product from hidden size 4096 on
+    assert L.plan(2048, 1024, 151936) == (True, True, True)
+    assert L.plan(2048, 5120, 152064) == (True, True, True)
+    assert L.plan(2048, 3584, 152064) == (False, True, True)  # the library's forward is 1-2 % ahead there
     assert L.plan(100, 1024, 151936) == (False, False, False)  # not a multiple of 64: the library's
     monkeypatch.setenv("PRL_LM_HEAD", "hip")
     assert L.plan(2048, 1024, 151936) == (True, True, True)
