@@ -86,6 +86,35 @@ def test_bad_arguments_are_rejected_with_a_message():
     assert lib.prl_last_error() == b""
 
 
+def test_lm_head_host_logic_needs_no_device():
+    """Which shapes the LM-head kernels take, what they refuse, and their workspace (the fp32 slabs of a K-split input
+    gradient, or the transposed hidden states for the weight gradient, whichever is larger)."""
+    lib = C.load()
+    null, one = ctypes.c_void_p(0), ctypes.c_void_p(16)
+    assert lib.prl_lm_head_supported(C.PRL_BF16, 2048, 1024, 151936) == 1
+    assert lib.prl_lm_head_supported(C.PRL_BF16, 16384, 5120, 152064) == 1
+    assert lib.prl_lm_head_supported(C.PRL_F32, 2048, 1024, 151936) == 0
+    assert lib.prl_lm_head_supported(C.PRL_BF16, 100, 1024, 151936) == 0   # T not a multiple of 64
+    assert lib.prl_lm_head_supported(C.PRL_BF16, 2048, 1000, 151936) == 0  # H not a multiple of 64
+    assert lib.prl_lm_head_supported(C.PRL_BF16, 2048, 1024, 1000) == 0    # V not a multiple of 64
+    # 16384 x 1024: 256 output tiles fill the chip without a K split: the workspace is the transposed hidden states
+    assert lib.prl_lm_head_workspace_bytes(16384, 1024, 151936) == 16384 * 1024 * 2
+    # 2048 x 1024: 32 output tiles: the input gradient is split over K into fp32 slabs
+    ws = lib.prl_lm_head_workspace_bytes(2048, 1024, 151936)
+    assert ws % (2048 * 1024 * 4) == 0 and 2 <= ws // (2048 * 1024 * 4) <= 16
+    assert lib.prl_lm_head_workspace_bytes(0, 1024, 151936) == 0
+    # refusals come before any launch
+    assert lib.prl_lm_head_fwd(null, 1024, one, 1024, one, 151936, 2048, 1024, 151936, null) == -1
+    assert b"null" in lib.prl_last_error()
+    assert lib.prl_lm_head_fwd(one, 1024, one, 1024, one, 151936, 100, 1024, 151936, null) == -1
+    assert b"unsupported" in lib.prl_last_error()
+    assert lib.prl_lm_head_fwd(one, 1000, one, 1024, one, 151936, 2048, 1024, 151936, null) == -1   # row stride < H
+    assert lib.prl_lm_head_bwd_input(one, 151936, one, 1024, one, 1024, 2048, 1024, 151936, null, 0, null) == -1
+    assert b"workspace" in lib.prl_last_error()
+    assert lib.prl_lm_head_bwd_weight(one, 151936, one, 1024, one, 1024, 2048, 1024, 151936, one, 16, null) == -1
+    assert b"workspace" in lib.prl_last_error()
+
+
 def test_no_cpu_fallback():
     x = torch.randn(1, 4, 10)
     idx = torch.zeros(1, 4, dtype=torch.long)
