@@ -422,8 +422,8 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
     //   end of phase 3's load section: Q of u+1 and the a0 pieces of P of u+1 (read from phase 0 of u+1 on); what
     //     may stay in flight: the a1 pieces of u+1 and the two pieces of Q of u+2 just issued;
     //   end of phase 1's load section: the a1 pieces of P of u (read in phase 2); in flight: all six younger
-    //     pieces.  Not in K-tile 0, whose pieces the wait in front of the loop has covered (and where stores of the
-    //     last tile may still be in flight, which a counted wait would wait for as well).
+    //     pieces.  (In an item's K-tile 0 this wait also covers the previous item's stores, issued a write-back's
+    //     time earlier; skipping it there makes the compiler peel the loop's first iteration and spill.)
 #define PRL_GEMM_TILE(S)                                                            \
   {                                                                                 \
     const bool n1 = u + 1 < nk, n2 = u + 2 < nk;                                    \
