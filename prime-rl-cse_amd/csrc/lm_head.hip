@@ -47,9 +47,8 @@ struct GemmArgs {
   int ktiles_per_split;  // K-tiles one work item walks
   int nsplit;
   int mtiles, ntiles;    // ceil(M / 256), ceil(N / 256)
-  int super_log2;        // a super-tile is (1 << super_log2) x (32 >> super_log2) tiles of C
-  int super_m, super_n;  // super-tiles along M and N
-  int total_items;       // 256 * ceil(super_m * super_n * nsplit / 8): work items, valid or not
+  int valid_items;       // mtiles * ntiles * nsplit: (tile, K split) pairs, in the order `gemm_item` walks them
+  int total_items;       // 256 * ceil(ceil(valid_items / 32) / 8): slots of that order dealt to the workgroups
   int cached_stores;     // bf16 tiles inside the matrix are stored with cacheable instead of non-temporal stores
   unsigned long long* stamps;  // diagnostic builds only (PRL_GEMM_STAMPS): 8 clock readings per work item, or NULL
 };
@@ -91,20 +90,24 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
 
 // Which tile and K split work item `item` is.  The kernel is persistent: 256 workgroups, one per compute unit,
 // workgroup b taking the items b, b + 256, ...  Workgroup b runs on XCD b % 8 (so do all its items), and the 32
-// items an XCD's compute units work on at a time are one "super-tile" of 8 x 4 (or 4 x 8, ... as the tile
-// counts allow) tiles of C of one K split, so that the operand panels they share are read from memory once and
-// from that XCD's L2 afterwards.  False: padding at the edge of a super-tile.
+// items an XCD's compute units work on at a time are 32 consecutive (tile, K split) pairs of ONE order: split by
+// split, and inside a split down strips of four tile columns (8 row tiles x 4 column tiles where the counts
+// allow), so that the operand panels they share are read from memory once and from that XCD's L2 afterwards.  The
+// order holds no padding: every group of 32 but the last is full, whatever the tile counts (ragged edges, K splits).
+// False: beyond the last pair.
 __device__ __forceinline__ bool gemm_item(const GemmArgs& a, int item, int& mt, int& nt, int& split) {
   const int xcd = item & 7, slot = item >> 3;
-  const int sid = (slot >> 5) * 8 + xcd, within = slot & 31;
-  const int per_split = a.super_m * a.super_n;
-  if (sid >= per_split * a.nsplit) return false;
-  split = sid / per_split;
-  const int s = sid - split * per_split;
-  const int sm = s % a.super_m, sn = s / a.super_m;
-  mt = (sm << a.super_log2) + (within & ((1 << a.super_log2) - 1));
-  nt = sn * (32 >> a.super_log2) + (within >> a.super_log2);
-  return mt < a.mtiles && nt < a.ntiles;
+  const int index = (((slot >> 5) * 8 + xcd) << 5) + (slot & 31);
+  if (index >= a.valid_items) return false;
+  const int per_split = a.mtiles * a.ntiles;
+  split = index / per_split;
+  const int r = index - split * per_split;
+  const int strip = r / (a.mtiles * 4);
+  const int within = r - strip * a.mtiles * 4;
+  const int width = a.ntiles - 4 * strip < 4 ? a.ntiles - 4 * strip : 4;
+  mt = within / width;
+  nt = 4 * strip + (within - mt * width);
+  return true;
 }
 
 template <int N>
@@ -590,19 +593,8 @@ static GemmArgs make_args(const void* P, int64_t ldp, const void* Q, int64_t ldq
   a.nsplit = (a.ktiles + a.ktiles_per_split - 1) / a.ktiles_per_split;  // no split without a K-tile
   a.mtiles = (int)((M + kBM - 1) / kBM);
   a.ntiles = (int)((N + kBN - 1) / kBN);
-  // the super-tile shape that pads least (8 x 4 tiles, 4 x 8, 2 x 16 or 1 x 32); the taller one on a tie
-  int64_t best = -1;
-  for (int lg = 3; lg >= 0; --lg) {
-    const int dm = 1 << lg, dn = 32 >> lg;
-    const int64_t padded = (int64_t)((a.mtiles + dm - 1) / dm) * ((a.ntiles + dn - 1) / dn);
-    if (best < 0 || padded < best) {
-      best = padded;
-      a.super_log2 = lg;
-    }
-  }
-  a.super_m = (a.mtiles + (1 << a.super_log2) - 1) >> a.super_log2;
-  a.super_n = (a.ntiles + (32 >> a.super_log2) - 1) / (32 >> a.super_log2);
-  a.total_items = 256 * ((a.super_m * a.super_n * a.nsplit + 7) / 8);
+  a.valid_items = a.mtiles * a.ntiles * a.nsplit;
+  a.total_items = 256 * ((((a.valid_items + 31) >> 5) + 7) >> 3);
   a.stamps = nullptr;
   a.cached_stores = a.ktiles_per_split <= 16;  // (only the forward product at H <= 1024 stores bf16 tiles that often)
   return a;
@@ -610,18 +602,23 @@ static GemmArgs make_args(const void* P, int64_t ldp, const void* Q, int64_t ldq
 // one workgroup per compute unit of the chip (the kernel walks over its work items); fewer when there is less work
 static unsigned gemm_grid(const GemmArgs& a) { return 256u; }
 
-// K splits for the input-gradient product: few tiles of C, a very long K.  The chip works the tiles off in rounds
-// of one per compute unit, so the time goes with ceil(tiles * splits / 256) / splits; the smallest split count
-// within 3 % of the best is taken (every split costs an fp32 slab written and read back).
+// K splits for the input-gradient product: few tiles of C, a very long K.  The chip works the (tile, split) pairs off
+// 32 per XCD and round, so a product of `tiles` tiles in s splits takes ceil(ceil(tiles * s / 32) / 8) rounds of
+// ceil(ktiles / s) K-tiles; every split also costs an fp32 slab written and read back (2 % each).  The cheapest
+// count up to 16 that leaves a split at least 8 K-tiles is taken.
 static int dx_splits(int64_t T, int64_t H, int64_t V) {
   const int64_t tiles = ((T + kBM - 1) / kBM) * ((H + kBN - 1) / kBN);
   const int64_t ktiles = V / kBK;
+  if (const char* e = getenv("PRL_LM_HEAD_DX_SPLITS")) {  // measurements only: a fixed split count
+    const int s = atoi(e);
+    if (s >= 1 && s <= 16 && (int64_t)s * 2 <= ktiles) return s;
+  }
   double best = 1e30;
   int best_s = 1;
   for (int s = 1; s <= 16 && s * 8 <= ktiles; ++s) {
-    const double rounds = (double)((tiles * s + 255) / 256);
-    const double cost = rounds / s * (1.0 + 0.02 * (s - 1));
-    if (cost < best * 0.97) {
+    const int64_t rounds = ((tiles * s + 31) / 32 + 7) / 8;
+    const double cost = (double)rounds * (double)((ktiles + s - 1) / s) * (1.0 + 0.02 * (s - 1));
+    if (cost < best * 0.995) {
       best = cost;
       best_s = s;
     }

@@ -300,15 +300,18 @@ GATHER_MULTIPLE = 256  # the number of gathered rows is rounded up to a multiple
 GATHER_AT_MOST = 0.9  # gather only when at most this share of a row's positions is left
 
 
-def gather_rule(tokens: int, hidden: int) -> tuple[int, float]:
+def gather_rule(tokens: int, hidden: int, library_products: bool = False) -> tuple[int, float]:
     """(multiple the number of gathered rows is rounded up to, largest share of a row's positions worth gathering).
 
-    Long rows of narrow models get a coarser rule.  The LM head's input gradient, [R, V] x [V, H], has few output
-    tiles and a very long sum; with H = 1024 or 2048 the GEMM library serves it at 1.2-1.3 PFLOP/s when R is
-    8192, 10240, 12288 or 16384 and at 0.6-0.9 at every other multiple of 256 (14336 included), so that 11776 rows
-    cost more than 12288 and 14336 as much as 16384 (`tools/lm_head_rows_sweep.py`); with H = 3584 the cost follows
-    R at every size."""
-    if tokens > 8192 and 0 < hidden <= 2048:
+    On this package's LM-head kernels (`lm_head.plan`; the default) the three products cost the same per row at
+    every row count (0.705-0.74 ms per 1024 rows at H = 1024, R = 8192 .. 16384 in steps of 512,
+    `tools/lm_head_rows_sweep.py`), so the plain rule holds.  With the products on the BLAS library
+    (`library_products`: PRL_LM_HEAD=lib, or shapes the kernels do not take) long rows of narrow models get a
+    coarser rule: the input gradient, [R, V] x [V, H], has few output tiles and a very long sum, and with H = 1024 or
+    2048 the library serves it at 1.2-1.3 PFLOP/s when R is 8192, 10240, 12288 or 16384 and at 0.6-0.9 at every
+    other multiple of 256 (14336 included), so that 11776 rows cost more than 12288 and 14336 as much as 16384; with
+    H = 3584 the library's cost follows R at every size."""
+    if library_products and tokens > 8192 and 0 < hidden <= 2048:
         return 2048, 0.76
     return GATHER_MULTIPLE, GATHER_AT_MOST
 
@@ -349,7 +352,11 @@ def scored_rows(host_micro_batch: MicroBatch, loss_config: LossConfig, model: nn
         return None
     import numpy as np
 
-    multiple, at_most = gather_rule(int(mask.shape[1]), int(getattr(getattr(model, "config", None), "hidden_size", 0)))
+    from . import lm_head
+
+    hidden = int(getattr(getattr(model, "config", None), "hidden_size", 0))
+    on_kernels = hidden > 0 and hidden % 64 == 0 and lm_head.plan(GATHER_MULTIPLE, hidden, vocab)[1]
+    multiple, at_most = gather_rule(int(mask.shape[1]), hidden, library_products=not on_kernels)
     n_scored = int(np.count_nonzero(mask.numpy()[0, 1:]))  # (cheap, and settles the rows where every token is scored)
     if n_scored == 0 or n_scored > at_most * (mask.shape[1] - 1):
         return None

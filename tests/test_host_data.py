@@ -205,17 +205,25 @@ def test_scored_rows_engage_only_where_they_apply(monkeypatch):
     assert T.scored_rows(most, tok, model(torch.bfloat16, 151936), "cpu").numel() == 1792  # ~1640 -> 1792 of 2047
     assert T.scored_rows({"loss_mask": torch.zeros(1, t, dtype=torch.bool)}, tok, model(torch.bfloat16, 151936), "cpu") is None
     # long rows of narrow models: multiples of 2048 rows, and only up to three quarters of the row
-    assert T.gather_rule(16384, 1024) == (2048, 0.76) and T.gather_rule(16384, 3584) == (256, 0.9)
-    assert T.gather_rule(8192, 1024) == (256, 0.9) and T.gather_rule(16384, 0) == (256, 0.9)
+    # the LM head's products on the BLAS library: coarse steps for long rows of narrow models
+    assert T.gather_rule(16384, 1024, True) == (2048, 0.76) and T.gather_rule(16384, 3584, True) == (256, 0.9)
+    assert T.gather_rule(8192, 1024, True) == (256, 0.9) and T.gather_rule(16384, 0, True) == (256, 0.9)
+    # on this package's kernels the cost follows the row count everywhere
+    assert T.gather_rule(16384, 1024) == (256, 0.9) and T.gather_rule(16384, 2048, False) == (256, 0.9)
     narrow = model(torch.bfloat16, 151936)
     narrow.config.hidden_size = 1024
     long_mask = torch.zeros(1, 16384, dtype=torch.bool)
-    long_mask[0, 1000:12000] = True  # 11000 scored tokens -> 12288 rows
-    assert T.scored_rows({"loss_mask": long_mask}, tok, narrow, "cpu").numel() == 12288
-    long_mask[0, 12000:13000] = True  # 12000 -> 12288 still
-    assert T.scored_rows({"loss_mask": long_mask}, tok, narrow, "cpu").numel() == 12288
-    long_mask[0, 13000:13400] = True  # 12400 would round up to 14336: the whole row instead
+    long_mask[0, 1000:12000] = True  # 11000 scored tokens
+    long_mask[0, 12000:13000] = True  # 12000
+    long_mask[0, 13000:13400] = True  # 12400
+    monkeypatch.setenv("PRL_LM_HEAD", "lib")  # the library's products: 12400 would round up to 14336: the whole row
     assert T.scored_rows({"loss_mask": long_mask}, tok, narrow, "cpu") is None
+    long_mask[0, 12000:] = False  # 11000 -> 12288 rows
+    assert T.scored_rows({"loss_mask": long_mask}, tok, narrow, "cpu").numel() == 12288
+    monkeypatch.delenv("PRL_LM_HEAD")  # this package's kernels: a multiple of 256, up to 0.9 of the row
+    assert T.scored_rows({"loss_mask": long_mask}, tok, narrow, "cpu").numel() == 11008
+    long_mask[0, 12000:13400] = True  # 12400 -> 12544
+    assert T.scored_rows({"loss_mask": long_mask}, tok, narrow, "cpu").numel() == 12544
     wide = model(torch.bfloat16, 152064)
     wide.config.hidden_size = 3584
     assert T.scored_rows({"loss_mask": long_mask}, tok, wide, "cpu").numel() == 12544  # 12400 -> a multiple of 256
