@@ -97,7 +97,7 @@ def plan(t: int, h: int, v: int) -> tuple[bool, bool, bool]:
     this package's kernels; the others go to the BLAS library through torch.
 
     Default (`PRL_LM_HEAD=auto`): the two backward products, where the kernels are ahead of the library at every
-    recipe shape measured (input gradient 1.05-2.15x, weight gradient 1.15-1.30x; `tools/lm_head_shapes.sh`), and
+    recipe shape measured (input gradient 1.07-2.06x, weight gradient 1.22-1.29x; `tools/lm_head_shapes.sh`), and
     the forward product except for hidden sizes between 2048 and 4096 (1.03-1.06x at 1024, level at 2048, 1.05x at
     5120; 1-2 % behind the library at 3584).  `PRL_LM_HEAD=hip` / `lib` take all three from one side;
     `PRL_LM_HEAD_FWD`, `PRL_LM_HEAD_DX`, `PRL_LM_HEAD_DW` = 0 / 1 set one product."""
