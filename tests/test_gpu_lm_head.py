@@ -36,6 +36,22 @@ def test_products_are_exact_on_integer_data(t, h, v):
     assert torch.equal(L.lm_head_bwd_weight(g, x), (g.float().t() @ x.float()).to(torch.bfloat16))
 
 
+def test_products_are_exact_on_random_small_shapes():
+    """Thirty shapes drawn from the multiples of 64 (tile counts 1 .. 7 per side, ragged strips of one to three tile
+    columns, one to 24 K-tiles, K splits of the input gradient with a short last split)."""
+    import random
+
+    dev = torch.device("cuda:0")
+    rng = random.Random(20240607)
+    for case in range(30):
+        t, h, v = (64 * rng.randint(1, 24) for _ in range(3))
+        gen = torch.Generator(device=dev).manual_seed(case)
+        x, w, g = _ints((t, h), -2, 2, gen, dev), _ints((v, h), -2, 2, gen, dev), _ints((t, v), -1, 1, gen, dev)
+        assert torch.equal(L.lm_head_fwd(x, w), (x.float() @ w.float().t()).to(torch.bfloat16)), (t, h, v, "fwd")
+        assert torch.equal(L.lm_head_bwd_input(g, w), (g.float() @ w.float()).to(torch.bfloat16)), (t, h, v, "dx")
+        assert torch.equal(L.lm_head_bwd_weight(g, x), (g.float().t() @ x.float()).to(torch.bfloat16)), (t, h, v, "dw")
+
+
 def _close(got, want32, k):
     # bf16 rounding of the result (2^-9 relative) plus fp32 accumulation over k terms of magnitude |a||b|
     tol = 2.0 ** -8 * want32.abs() + 1e-6 * k ** 0.5 * want32.abs().max()
