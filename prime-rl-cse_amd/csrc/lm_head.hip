@@ -636,8 +636,12 @@ extern "C" void prl_lm_head_set_stamps(void* p) { g_stamps = (unsigned long long
 #endif
 
 extern "C" int prl_lm_head_supported(int dtype, int64_t T, int64_t H, int64_t V) {
-  return dtype == PRL_BF16 && T >= 1 && H >= kBK && V >= 8 && H % kBK == 0 && V % kBK == 0 && T % kBK == 0 &&
-         T < (1 << 30) && V < (1 << 30) && H < (1 << 30);
+  if (!(dtype == PRL_BF16 && T >= 1 && H >= kBK && V >= 8 && H % kBK == 0 && V % kBK == 0 && T % kBK == 0 &&
+        T < (1 << 30) && V < (1 << 30) && H < (1 << 30)))
+    return 0;
+  // the kernels count (tile, K split) pairs in 32 bits: at most 2^24 tiles per product (16 splits at most)
+  const int64_t tt = (T + kBM - 1) / kBM, th = (H + kBM - 1) / kBM, tv = (V + kBM - 1) / kBM;
+  return tt * tv <= (1 << 24) && tt * th <= (1 << 24) && th * tv <= (1 << 24);
 }
 
 extern "C" size_t prl_lm_head_workspace_bytes(int64_t T, int64_t H, int64_t V) {
