@@ -50,7 +50,8 @@ struct GemmArgs {
   int valid_items;       // mtiles * ntiles * nsplit: (tile, K split) pairs, in the order `gemm_item` walks them
   int total_items;       // 256 * ceil(ceil(valid_items / 32) / 8): slots of that order dealt to the workgroups
   int cached_stores;     // bf16 tiles inside the matrix are stored with cacheable instead of non-temporal stores
-  unsigned long long* stamps;  // diagnostic builds only (PRL_GEMM_STAMPS): 8 clock readings per work item, or NULL
+  unsigned long long* stamps;  // diagnostic builds only (PRL_GEMM_STAMPS): per workgroup 4 phase sums, items, clocks
+  unsigned long long* stamps2;  // the same builds: per workgroup, shader cycles in each of a K-tile's 8 sections (wave 0)
 };
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
@@ -131,6 +132,13 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
   unsigned long long phase_sum[4] = {0, 0, 0, 0}, stamp_first = wall_clock64(), stamp_last = stamp_first;
   const unsigned long long cycles_first = clock64();  // shader clock: its rate against the 100 MHz clock is the frequency
   int stamped = 0;
+  unsigned long long section_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, section_last = 0;  // shader cycles per section of a K-tile
+#define PRL_SECTION(k)                                        \
+  {                                                           \
+    const unsigned long long now = clock64();                 \
+    section_sum[k] += now - section_last;                     \
+    section_last = now;                                       \
+  }
 #define PRL_STAMP(i)                                  \
   {                                                   \
     const unsigned long long now = wall_clock64();    \
@@ -139,6 +147,7 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
   }
 #else
 #define PRL_STAMP(i)
+#define PRL_SECTION(k)
 #endif
   const int stride = (int)gridDim.x;
   int item = (int)blockIdx.x, mt = 0, nt = 0, split = 0;
@@ -434,21 +443,27 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
     load_a((S), 0);                                                                 \
     load_b((S), 0, bx);                                                             \
     bar();                                                                          \
+    PRL_SECTION(1)                                                                  \
     wait_tr_reads(bx);                                                              \
     mma(0, 0, bx);                                                                  \
     bar();                                                                          \
+    PRL_SECTION(2)                                                                  \
     if (n1) { issue_p((S) ^ 1, 0); issue_p((S) ^ 1, 2); }                           \
     load_b((S), 1, by);                                                             \
     if (n1) wait_vmcnt<6>(); else wait_vmcnt<0>();                                  \
     bar();                                                                          \
+    PRL_SECTION(3)                                                                  \
     wait_tr_reads(by);                                                              \
     mma(0, 1, by);                                                                  \
     bar();                                                                          \
+    PRL_SECTION(4)                                                                  \
     if (n1) { issue_p((S) ^ 1, 1); issue_p((S) ^ 1, 3); }                           \
     load_a((S), 1);                                                                 \
     bar();                                                                          \
+    PRL_SECTION(5)                                                                  \
     mma(1, 1, by);                                                                  \
     bar();                                                                          \
+    PRL_SECTION(6)                                                                  \
     if (n2) {                                                                       \
       issue_q((S), 0);                                                              \
       issue_q((S), 1);                                                              \
@@ -457,10 +472,15 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
       wait_vmcnt<2>();                                                              \
     }                                                                               \
     bar();                                                                          \
+    PRL_SECTION(7)                                                                  \
     mma(1, 0, bx);                                                                  \
     bar();                                                                          \
+    PRL_SECTION(0)                                                                  \
   }
 
+#ifdef PRL_GEMM_STAMPS
+    section_last = clock64();
+#endif
     {
       int u = 0;
       for (; u + 1 < nk; ++u) {
@@ -541,6 +561,7 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
     out[5] = stamp_first;
     out[6] = stamp_last;
     out[7] = clock64() - cycles_first;
+    if (a.stamps2) for (int i = 0; i < 8; ++i) a.stamps2[(size_t)blockIdx.x * 8 + i] = section_sum[i];
   }
 #endif
 }
@@ -596,6 +617,7 @@ static GemmArgs make_args(const void* P, int64_t ldp, const void* Q, int64_t ldq
   a.valid_items = a.mtiles * a.ntiles * a.nsplit;
   a.total_items = 256 * ((((a.valid_items + 31) >> 5) + 7) >> 3);
   a.stamps = nullptr;
+  a.stamps2 = nullptr;
   a.cached_stores = a.ktiles_per_split <= 16;  // (only the forward product at H <= 1024 stores bf16 tiles that often)
   return a;
 }
@@ -632,7 +654,9 @@ using namespace prl;
 
 #ifdef PRL_GEMM_STAMPS
 static unsigned long long* g_stamps = nullptr;
+static unsigned long long* g_stamps2 = nullptr;
 extern "C" void prl_lm_head_set_stamps(void* p) { g_stamps = (unsigned long long*)p; }
+extern "C" void prl_lm_head_set_section_stamps(void* p) { g_stamps2 = (unsigned long long*)p; }
 #endif
 
 extern "C" int prl_lm_head_supported(int dtype, int64_t T, int64_t H, int64_t V) {
@@ -665,6 +689,7 @@ extern "C" int prl_lm_head_fwd(const void* hidden, int64_t hidden_stride, const 
   GemmArgs a = make_args(hidden, hidden_stride, weight, weight_stride, logits, logits_stride, T, V, H, 1);
 #ifdef PRL_GEMM_STAMPS
   a.stamps = g_stamps;
+  a.stamps2 = g_stamps2;
 #endif
   hipLaunchKernelGGL((k_lm_gemm<true, kOutBf16>), dim3(gemm_grid(a)), dim3(kGemmThreads), 0, (hipStream_t)stream, a);
   PRL_CHECK_LAUNCH("k_lm_gemm (forward)");

@@ -41,3 +41,21 @@ for i, name in enumerate(names):
 print(f"whole item: {float((s[:, :4].sum(1) * 0.01 / items).mean()):.2f} us")
 mhz = s[:, 7] / ((s[:, 6] - s[:, 5]) * 0.01)
 print(f"shader clock while the kernel ran: mean {float(mhz.mean()):.0f} MHz  min {float(mhz.min()):.0f}  max {float(mhz.max()):.0f}")
+# shader cycles per interval of a K-tile (wave 0 of every workgroup; an interval lasts until BOTH groups of waves have
+# reached the next barrier, so it is the longer of the two sections named)
+if hasattr(lib, "prl_lm_head_set_section_stamps"):
+    sec = torch.zeros(256 * 8, dtype=torch.int64, device=dev)
+    lib.prl_lm_head_set_section_stamps(ctypes.c_void_p(sec.data_ptr()))
+    lib.prl_lm_head_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
+    L.lm_head_fwd(x, w)
+    torch.cuda.synchronize()
+    lib.prl_lm_head_set_section_stamps(None)
+    lib.prl_lm_head_set_stamps(None)
+    c = sec.view(256, 8).cpu().double()
+    tiles = float(items.mean()) * (h // 64)
+    names = {1: "load 0 | MFMA 3", 2: "MFMA 0 | load 0", 3: "load 1 | MFMA 0", 4: "MFMA 1 | load 1", 5: "load 2 | MFMA 1",
+             6: "MFMA 2 | load 2", 7: "load 3 | MFMA 2", 0: "MFMA 3 | load 3"}
+    print("cycles per interval of a K-tile (waves 0-3 | waves 4-7), with the stamps' own cost in every one:")
+    for k in (1, 2, 3, 4, 5, 6, 7, 0):
+        print(f"  {names[k]:18s} {float(c[:, k].mean()) / tiles:7.1f}")
+    print(f"  sum {float(c.sum(1).mean()) / tiles:7.1f} per K-tile; 16 MFMAs are 256 cycles")
