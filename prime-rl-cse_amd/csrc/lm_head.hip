@@ -215,6 +215,7 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) issue_q(0, j);
   };
+  constexpr int kAhead = 2;  // pieces of K-tile 1 requested with K-tile 0: half of Q
   auto issue_q1 = [&]() {
     if (nk > 1) {
       issue_q(1, 0);
@@ -408,9 +409,9 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
     const bool inside = m0 + kBM <= a.M && n0 + kBN <= a.N;
     // K-tile 0 has landed: everything but the two pieces of K-tile 1 and the stores issued behind K-tile 0's loads
     if (behind) {
-      if (nk > 1) wait_vmcnt<2 + late_stores<OUT>()>(); else wait_vmcnt<late_stores<OUT>()>();
+      if (nk > 1) wait_vmcnt<kAhead + late_stores<OUT>()>(); else wait_vmcnt<late_stores<OUT>()>();
     } else {
-      if (nk > 1) wait_vmcnt<2>(); else wait_vmcnt<0>();
+      if (nk > 1) wait_vmcnt<kAhead>(); else wait_vmcnt<0>();
     }
     bar();
     PRL_STAMP(1)
