@@ -405,6 +405,15 @@ int prl_accumulate(const void* const* src, int src_dtype, const int64_t* dst_off
 int prl_accumulate_first(const void* const* src, int src_dtype, const int64_t* dst_offset, const int64_t* numel,
                    const int32_t* chunk_tensor, const int64_t* chunk_start, int64_t n_chunks, const float* scale,
                    float* acc, void* stream);
+/* Either of the two (`first` != 0: prl_accumulate_first), and chunk_squares[c] = the sum of the squares of chunk c's
+ * new sums, for every chunk whose tensor has a gradient in this call (and 0 for one without, when `first`); other
+ * entries stay as they are.  When the first call of a step is a `first` one over all chunks and every later call
+ * of the step goes through here with the same chunk table, the entries add up to the squared norm of `acc`: the
+ * gradient norm that clipping needs (torch.nn.utils.clip_grad_norm_, src/prime_rl/trainer/rl/train.py:336-338)
+ * without another pass over the sums.  `chunk_squares`: n_chunks floats of device memory. */
+int prl_accumulate_squares(int first, const void* const* src, int src_dtype, const int64_t* dst_offset,
+                           const int64_t* numel, const int32_t* chunk_tensor, const int64_t* chunk_start,
+                           int64_t n_chunks, const float* scale, float* acc, float* chunk_squares, void* stream);
 
 /*
  * out[i] = part[0][i] + part[1][i] + ... + part[nparts - 1][i] for i < n, added in that order in fp32 and rounded

@@ -102,6 +102,10 @@ SIGNATURES = {
         c_int,
         [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p],
     ),
+    "prl_accumulate_squares": (
+        c_int,
+        [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
     "prl_attn_short_supported": (c_int, [c_int, c_int64, c_int64, c_int64, c_int64]),
     "prl_attn_short_fwd": (
         c_int,

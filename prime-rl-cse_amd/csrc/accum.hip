@@ -16,14 +16,22 @@ constexpr int kAccumChunk = 8192;  // elements per workgroup: 16 KB of bf16 in, 
 
 // FIRST: the sums start here (acc = scale * src, zeros where a tensor has no gradient) instead of continuing
 // (acc += scale * src): the first pass of a step then needs neither a cleared buffer nor a read of it.
-template <int DT, bool FIRST>
+//
+// SQ: the workgroup also leaves the sum of the squares of its chunk's NEW sums in chunk_squares[blockIdx.x].  A
+// chunk that a launch does not touch (no gradient, not FIRST) keeps its entry, which is still right; so once a
+// FIRST launch has written every entry and every later launch of the step is an SQ one, the entries add up to the
+// squared norm of the whole buffer, and the step's gradient norm costs one read of 4 bytes per 8192 elements
+// instead of one more pass over the sums.
+template <int DT, bool FIRST, bool SQ>
 __global__ __launch_bounds__(kAccumThreads) void k_accumulate(const void* const* __restrict__ src,
                                                              const int64_t* __restrict__ dst_offset,
                                                              const int64_t* __restrict__ numel,
                                                              const int32_t* __restrict__ chunk_tensor,
                                                              const int64_t* __restrict__ chunk_start,
                                                              const float* __restrict__ scale,
-                                                             float* __restrict__ acc) {
+                                                             float* __restrict__ acc,
+                                                             float* __restrict__ chunk_squares) {
+  __shared__ float slots[kAccumThreads / kWave];
   const int tensor = chunk_tensor[blockIdx.x];
   const char* s = static_cast<const char*>(src[tensor]);
   if (!FIRST && s == nullptr) return;  // a parameter that got no gradient in this backward
@@ -34,8 +42,10 @@ __global__ __launch_bounds__(kAccumThreads) void k_accumulate(const void* const*
   float* d = acc + dst_offset[tensor] + start;
   if (FIRST && s == nullptr) {  // the first pass of a step starts every sum: this one at zero
     for (int64_t i = threadIdx.x; i < n; i += kAccumThreads) d[i] = 0.0f;
+    if (SQ && threadIdx.x == 0) chunk_squares[blockIdx.x] = 0.0f;
     return;
   }
+  float ss = 0.0f;
   constexpr int ES = DT == PRL_F32 ? 4 : 2;
   s += start * ES;
   // 8 elements per lane and turn where both sides are 16-byte aligned (the host aligns the flat buffer's
@@ -58,6 +68,10 @@ __global__ __launch_bounds__(kAccumThreads) void k_accumulate(const void* const*
     a.x = fmaf(x[0], sc, a.x), a.y = fmaf(x[1], sc, a.y), a.z = fmaf(x[2], sc, a.z), a.w = fmaf(x[3], sc, a.w);
     b.x = fmaf(x[4], sc, b.x), b.y = fmaf(x[5], sc, b.y), b.z = fmaf(x[6], sc, b.z), b.w = fmaf(x[7], sc, b.w);
     dp[0] = a, dp[1] = b;
+    if (SQ) {
+      ss += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+      ss += (b.x * b.x + b.y * b.y) + (b.z * b.z + b.w * b.w);
+    }
   }
   for (int64_t i = (nvec << 3) + threadIdx.x; i < n; i += kAccumThreads) {
     float x;
@@ -66,7 +80,13 @@ __global__ __launch_bounds__(kAccumThreads) void k_accumulate(const void* const*
     } else {
       x = __uint_as_float((uint32_t)reinterpret_cast<const uint16_t*>(s)[i] << 16);
     }
-    d[i] = FIRST ? x * sc : fmaf(x, sc, d[i]);
+    const float y = FIRST ? x * sc : fmaf(x, sc, d[i]);
+    d[i] = y;
+    if (SQ) ss += y * y;
+  }
+  if (SQ) {  // (every thread of the workgroup gets here: the early returns above are taken by all or by none)
+    ss = block_sum<kAccumThreads / kWave>(ss, slots);
+    if (threadIdx.x == 0) chunk_squares[blockIdx.x] = ss;
   }
 }
 
@@ -78,7 +98,7 @@ extern "C" int64_t prl_accumulate_chunk_elems(void) { return kAccumChunk; }
 
 static int accumulate(bool first, const void* const* src, int src_dtype, const int64_t* dst_offset,
                       const int64_t* numel, const int32_t* chunk_tensor, const int64_t* chunk_start, int64_t n_chunks,
-                      const float* scale, float* acc, void* stream) {
+                      const float* scale, float* acc, float* chunk_squares, void* stream) {
   clear_error();
   PRL_REQUIRE(n_chunks >= 0 && n_chunks <= 0x7fffffffLL, "accumulate: n_chunks=%lld out of range", (long long)n_chunks);
   PRL_REQUIRE(src_dtype == PRL_F32 || src_dtype == PRL_BF16, "accumulate: unsupported gradient dtype %d", src_dtype);
@@ -87,14 +107,21 @@ static int accumulate(bool first, const void* const* src, int src_dtype, const i
               "accumulate: the tables and the accumulator must not be NULL");
   const dim3 grid((unsigned)n_chunks), block(kAccumThreads);
   hipStream_t st = (hipStream_t)stream;
-#define PRL_ACC(DT, FIRST)                                                                                         \
-  hipLaunchKernelGGL((k_accumulate<DT, FIRST>), grid, block, 0, st, src, dst_offset, numel, chunk_tensor, chunk_start, \
-                     scale, acc)
-  if (src_dtype == PRL_F32) {
-    if (first) PRL_ACC(PRL_F32, true); else PRL_ACC(PRL_F32, false);
-  } else {
-    if (first) PRL_ACC(PRL_BF16, true); else PRL_ACC(PRL_BF16, false);
+#define PRL_ACC(DT, FIRST, SQ)                                                                                   \
+  hipLaunchKernelGGL((k_accumulate<DT, FIRST, SQ>), grid, block, 0, st, src, dst_offset, numel, chunk_tensor,      \
+                     chunk_start, scale, acc, chunk_squares)
+#define PRL_ACC_FORM(DT)                                                      \
+  if (chunk_squares) {                                                        \
+    if (first) PRL_ACC(DT, true, true); else PRL_ACC(DT, false, true);        \
+  } else {                                                                    \
+    if (first) PRL_ACC(DT, true, false); else PRL_ACC(DT, false, false);      \
   }
+  if (src_dtype == PRL_F32) {
+    PRL_ACC_FORM(PRL_F32)
+  } else {
+    PRL_ACC_FORM(PRL_BF16)
+  }
+#undef PRL_ACC_FORM
 #undef PRL_ACC
   PRL_CHECK_LAUNCH("accumulate");
   return PRL_OK;
@@ -103,13 +130,25 @@ static int accumulate(bool first, const void* const* src, int src_dtype, const i
 extern "C" int prl_accumulate(const void* const* src, int src_dtype, const int64_t* dst_offset, const int64_t* numel,
                               const int32_t* chunk_tensor, const int64_t* chunk_start, int64_t n_chunks,
                               const float* scale, float* acc, void* stream) {
-  return accumulate(false, src, src_dtype, dst_offset, numel, chunk_tensor, chunk_start, n_chunks, scale, acc, stream);
+  return accumulate(false, src, src_dtype, dst_offset, numel, chunk_tensor, chunk_start, n_chunks, scale, acc, nullptr,
+                    stream);
 }
 
 extern "C" int prl_accumulate_first(const void* const* src, int src_dtype, const int64_t* dst_offset,
                                     const int64_t* numel, const int32_t* chunk_tensor, const int64_t* chunk_start,
                                     int64_t n_chunks, const float* scale, float* acc, void* stream) {
-  return accumulate(true, src, src_dtype, dst_offset, numel, chunk_tensor, chunk_start, n_chunks, scale, acc, stream);
+  return accumulate(true, src, src_dtype, dst_offset, numel, chunk_tensor, chunk_start, n_chunks, scale, acc, nullptr,
+                    stream);
+}
+
+extern "C" int prl_accumulate_squares(int first, const void* const* src, int src_dtype, const int64_t* dst_offset,
+                                      const int64_t* numel, const int32_t* chunk_tensor, const int64_t* chunk_start,
+                                      int64_t n_chunks, const float* scale, float* acc, float* chunk_squares,
+                                      void* stream) {
+  clear_error();
+  PRL_REQUIRE(chunk_squares != nullptr || n_chunks == 0, "accumulate_squares: chunk_squares must not be NULL");
+  return accumulate(first != 0, src, src_dtype, dst_offset, numel, chunk_tensor, chunk_start, n_chunks, scale, acc,
+                    chunk_squares, stream);
 }
 
 // ---------------------------------------------------------------- sum of partial products

@@ -235,7 +235,7 @@ class FlatState:
                 x.gather_work = None
 
     def finish_step(self, optimizer: torch.optim.Optimizer, max_norm: float | None, keep_sums: bool = False,
-                    gathers_in_flight: bool = False) -> Tensor:
+                    gathers_in_flight: bool = False, squared_norm: Tensor | None = None) -> Tensor:
         """Mean of the ranks' gradient sums, clip by the global norm, optimizer step on the shard, new compute
         copy on every rank.  Returns the gradient norm before clipping (a 0-d tensor on the device; reading it
         is the caller's one host synchronisation).  Same clipping rule as torch.nn.utils.clip_grad_norm_,
@@ -243,21 +243,28 @@ class FlatState:
         sums as they are (for a caller whose next step overwrites them); otherwise they are cleared.  Buckets
         whose reduction a caller has already started (`reduce_bucket`) are only waited for.  With
         `gathers_in_flight` the all-gathers of the new compute copy (RCCL) are left running and it is the caller
-        who makes a stream wait for a bucket before reading it (`wait_gathered`)."""
+        who makes a stream wait for a bucket before reading it (`wait_gathered`).  `squared_norm` (one rank only): the
+        squared norm of the gradient sums as a 0-d fp32 tensor, from a caller who has it already."""
+        if squared_norm is not None and self.exchange:
+            raise ValueError("finish_step: `squared_norm` is for a rank that exchanges nothing")
         try:
-            return self._finish_step(optimizer, max_norm, keep_sums)
+            return self._finish_step(optimizer, max_norm, keep_sums, squared_norm)
         finally:
             if not gathers_in_flight:
                 self.wait_gathered()
 
-    def _finish_step(self, optimizer: torch.optim.Optimizer, max_norm: float | None, keep_sums: bool) -> Tensor:
+    def _finish_step(self, optimizer: torch.optim.Optimizer, max_norm: float | None, keep_sums: bool,
+                     squared_norm: Tensor | None = None) -> Tensor:
         self.wait_gathered()  # (a step without any forward: the last step's weights must have arrived)
         if self.exchange:
             self.wait_reduced()
             grad = self._shard_grad
         else:
             grad = self.acc32
-        sq = torch.linalg.vector_norm(grad, 2, dtype=torch.float32).square()
+        if squared_norm is not None:
+            sq = squared_norm
+        else:
+            sq = torch.linalg.vector_norm(grad, 2, dtype=torch.float32).square()
         if self.exchange:
             if self._gloo():
                 host = sq.cpu()
@@ -463,6 +470,12 @@ class Replica:
         # captured pass is the same launch whichever pass of a step replays it, so with graphs every pass adds
         # and the optimizer step clears.
         self._starts_sums = False
+        # One rank, no graphs: every accumulation launch also leaves the sum of squares of each chunk it has written,
+        # and the step's gradient norm is the sum of those few numbers instead of one more pass over 4 bytes per
+        # parameter.  `_squares_whole`: a pass that started the sums has written every chunk's entry in this step.
+        self._norm_from_chunks = (os.environ.get("PRL_NORM_FROM_CHUNKS", "1") != "0" and not graphs
+                                  and not self.state.exchange)
+        self._squares_whole = False
         # the chunk table of the accumulation kernel: parameter sizes never change
         lib = C.load()
         chunk = int(lib.prl_accumulate_chunk_elems())
@@ -476,6 +489,8 @@ class Replica:
         self._chunk_start = torch.from_numpy(np.concatenate(start_of)).to(self.device)
         self._numel = torch.tensor(st.numel, dtype=torch.int64).to(self.device)
         self._offsets = torch.tensor(st.offsets, dtype=torch.int64).to(self.device)
+        self._chunk_squares = torch.zeros(self._chunk_tensor.numel() if self._norm_from_chunks else 0,
+                                          dtype=torch.float32, device=self.device)
         unit_gradient(self.device)  # exists before any capture
         # the exchange overlapped with backward: which chunks belong to which bucket, and the hooks that tell
         # when a bucket's last gradient has landed / when a module is about to read a bucket's weights
@@ -633,15 +648,25 @@ class Replica:
     def _accumulate(self, src: Tensor, first: bool = False) -> None:
         """`first`: the sums start with this pass (nothing cleared them, their old contents are not read)."""
         lib = C.load()
-        entry = lib.prl_accumulate_first if first else lib.prl_accumulate
+        args = (C.ptr(src), C.dtype_code(self.state.flat16), C.ptr(self._offsets), C.ptr(self._numel),
+                C.ptr(self._chunk_tensor), C.ptr(self._chunk_start), self._chunk_tensor.numel(), C.ptr(self._scale),
+                C.ptr(self.state.acc32))
         with C.on_device(self.device):
-            C.check(
-                entry(C.ptr(src), C.dtype_code(self.state.flat16), C.ptr(self._offsets),
-                                   C.ptr(self._numel), C.ptr(self._chunk_tensor), C.ptr(self._chunk_start),
-                                   self._chunk_tensor.numel(), C.ptr(self._scale), C.ptr(self.state.acc32),
-                                   C.stream_ptr(self.device)),
-                "prl_accumulate",
-            )
+            if self._norm_from_chunks:
+                C.check(lib.prl_accumulate_squares(int(first), *args, C.ptr(self._chunk_squares),
+                                                   C.stream_ptr(self.device)), "prl_accumulate_squares")
+                self._squares_whole = self._squares_whole or first
+            else:
+                entry = lib.prl_accumulate_first if first else lib.prl_accumulate
+                C.check(entry(*args, C.stream_ptr(self.device)), "prl_accumulate")
+
+    def _squared_norm(self) -> Tensor | None:
+        """The squared norm of the step's gradient sums from the accumulation kernel's per-chunk sums of squares
+        (added in fp64), or None when they do not cover the whole buffer; the step is over either way."""
+        whole, self._squares_whole = self._squares_whole, False
+        if not whole:
+            return None
+        return self._chunk_squares.sum(dtype=torch.float64).float()
 
     def _embedding_backward(self, input_ids: Tensor, grad_rows: Tensor) -> None:
         """The embedding table's share of a micro-batch's gradient, from the gradient of the looked-up rows:
@@ -835,6 +860,7 @@ class Replica:
         rows_b, units_b, rows, units = prepared["rows_b"], prepared["units_b"], prepared["rows"], prepared["units"]
         recomputed_errors = prepared["recomputed_errors"]
         self._starts_sums = not self.graphs
+        self._squares_whole = False
         self._scale.fill_(inv_scale)
         tensors = Tensors()
         vocab = int(self.model.config.vocab_size)
@@ -893,13 +919,14 @@ class Replica:
                 # small launches (and one host synchronisation): 4 ms of norm and optimizer kernels then run
                 # while the host issues them, instead of the GPU waiting 0.3-0.5 ms for each in turn.
                 grad_norm = self.state.finish_step(self.optimizer, max_norm, keep_sums=not self.graphs,
-                                                   gathers_in_flight=self.overlap)
+                                                   gathers_in_flight=self.overlap, squared_norm=self._squared_norm())
             book(rows[step_idx] if rows is not None else None, mb, loss, aux, pieces_of(rows, step_idx, given_row)[0],
                  recomputed_errors[step_idx] if recomputed_errors is not None else None)
         # one loss per given micro-batch, as the reference logs it; 0 for those not run (nothing scored)
         tensors.add("loss", losses_per_given_row(loss_parts, loss_rows, n_given, self.device))
         if not units:  # nothing to learn from on this rank: its share of the mean is zero, not last step's sums
             self.state.acc32.zero_()
+            self._squares_whole = False
             if self.overlap:
                 # the other ranks start their reduce-scatters from inside a backward pass: every bucket but the
                 # embedding table's back to front, then that one; collectives have to come in one order everywhere

@@ -94,6 +94,56 @@ def test_accumulate_kernel_against_torch(dtype):
     torch.testing.assert_close(got, first, rtol=0, atol=0)
     assert lib.prl_accumulate(C.ptr(ptrs), 99, C.ptr(offs), C.ptr(numel), C.ptr(ct), C.ptr(cs), ct.numel(), None,
                               C.ptr(acc), None) != 0
+    # with per-chunk sums of squares: the same sums bit for bit, and after a first pass and a later one (in which
+    # other tensors have no gradient) the entries are those of the buffer as it stands
+    squares = torch.full((ct.numel(),), float("nan"), device=DEV)
+    again = torch.full_like(acc, float("nan"))
+    stream = C.stream_ptr(torch.device(DEV))
+    C.check(lib.prl_accumulate_squares(1, C.ptr(ptrs), C.dtype_code(srcs[0]), C.ptr(offs), C.ptr(numel), C.ptr(ct),
+                                       C.ptr(cs), ct.numel(), C.ptr(scale), C.ptr(again), C.ptr(squares), stream), "sq")
+    later = [None if k in (0, 3, 5) else s for k, s in enumerate(srcs)]
+    ptrs2 = torch.tensor([0 if s is None else s.data_ptr() for s in later], dtype=torch.int64).to(DEV)
+    C.check(lib.prl_accumulate_squares(0, C.ptr(ptrs2), C.dtype_code(srcs[0]), C.ptr(offs), C.ptr(numel), C.ptr(ct),
+                                       C.ptr(cs), ct.numel(), C.ptr(scale), C.ptr(again), C.ptr(squares), stream), "sq")
+    two = first.clone()
+    for s_, o, n in zip(later, offsets, sizes):
+        if s_ is not None:
+            two[o : o + n] = torch.addcmul(two[o : o + n], s_.float(), scale)
+    for o, n in zip(offsets, sizes):
+        assert torch.equal(again[o : o + n], two[o : o + n])
+    want_sq = torch.stack([two[offsets[k] + c0 : offsets[k] + min(c0 + chunk, sizes[k])].double().square().sum()
+                           for k, c0 in zip(tensor_of.tolist(), start_of.tolist())])
+    torch.testing.assert_close(squares.double(), want_sq, rtol=2e-6, atol=0)
+    assert lib.prl_accumulate_squares(1, C.ptr(ptrs), C.dtype_code(srcs[0]), C.ptr(offs), C.ptr(numel), C.ptr(ct),
+                                      C.ptr(cs), ct.numel(), None, C.ptr(again), None, None) != 0
+
+
+def test_gradient_norm_from_the_accumulation_kernel_is_the_norm_of_the_sums(monkeypatch):
+    """One rank without graphs takes the step's gradient norm from the per-chunk sums of squares that the
+    accumulation launches leave; a pass over the finished sums (PRL_NORM_FROM_CHUNKS=0) gives the same steps."""
+    from prime_rl_cse_amd.optim import FlatAdamW
+
+    gen = torch.Generator().manual_seed(61)
+    batches = [rows(gen, 3, [20, 12, 32], 4096) for _ in range(3)]
+    batches[1][2]["loss_mask"][:] = False  # (a pass that is left out: the sums start with another one)
+    outs = []
+    for switch in ("1", "0"):
+        monkeypatch.setenv("PRL_NORM_FROM_CHUNKS", switch)
+        model = T.get_model(tiny_config(vocab=4096), DEV, torch.float32, seed=11)
+        rep = Replica(model, lambda m: FlatAdamW(m.parameters(), lr=1e-3, weight_decay=0.01))
+        assert rep._norm_from_chunks == (switch == "1")
+        out = []
+        for mbs in copy.deepcopy(batches):
+            res = rep.train_step(mbs, prl.LossConfig(), max_norm=0.05)
+            true_norm = rep.state.acc32.double().norm().item()  # (the sums are kept until the next step starts them)
+            out.append((res.grad_norm, true_norm, rep.state.master.detach().clone()))
+        outs.append(out)
+    for (n1, t1, m1), (n0, t0, m0) in zip(*outs):
+        assert n1 > 0.05  # (clipping is at work: the norm decides the step)
+        assert abs(n1 - t1) <= 2e-6 * t1 and abs(n0 - t0) <= 2e-6 * t0
+        # (the two norms differ in the last bit or two, and so do the clipped gradients; Adam's division turns that
+        # into up to a percent of lr = 1e-3 where a gradient is next to nothing)
+        torch.testing.assert_close(m1, m0, rtol=0, atol=1e-5)
 
 
 @pytest.mark.parametrize("graphs", [False, pytest.param(True, marks=pytest.mark.skip(reason=REPLAY_OFF))])
