@@ -568,10 +568,11 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
 }
 
 // out[c][r] = in[r][c] for a bf16 [rows][cols] matrix: 64 x 64 blocks through LDS, 16-byte loads and stores.
+// Blocks of rows along grid x (the token count, which has no bound to speak of), blocks of columns along grid y.
 __global__ void __launch_bounds__(256) k_transpose_bf16(const uint16_t* __restrict__ in, int64_t ld_in,
                                                        uint16_t* __restrict__ out, int64_t ld_out, int rows, int cols) {
   __shared__ uint16_t tile[64][72];
-  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   const int tid = threadIdx.x;
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
@@ -622,8 +623,9 @@ static GemmArgs make_args(const void* P, int64_t ldp, const void* Q, int64_t ldq
   a.cached_stores = a.ktiles_per_split <= 16;  // (only the forward product at H <= 1024 stores bf16 tiles that often)
   return a;
 }
-// one workgroup per compute unit of the chip (the kernel walks over its work items); fewer when there is less work
-static unsigned gemm_grid(const GemmArgs& a) { return 256u; }
+// One workgroup per compute unit of an MI355X, whatever the product's size: the kernel walks over its work items,
+// which `gemm_item` deals out in rounds of 256 (`total_items`), and a workgroup without a valid item ends at once.
+static unsigned gemm_grid(const GemmArgs&) { return 256u; }
 
 // K splits for the input-gradient product: few tiles of C, a very long K.  The chip works the (tile, split) pairs off
 // 32 per XCD and round, so a product of `tiles` tiles in s splits takes ceil(ceil(tiles * s / 32) / 8) rounds of
@@ -662,7 +664,7 @@ extern "C" void prl_lm_head_set_section_stamps(void* p) { g_stamps2 = (unsigned 
 
 extern "C" int prl_lm_head_supported(int dtype, int64_t T, int64_t H, int64_t V) {
   if (!(dtype == PRL_BF16 && T >= 1 && H >= kBK && V >= 8 && H % kBK == 0 && V % kBK == 0 && T % kBK == 0 &&
-        T < (1 << 30) && V < (1 << 30) && H < (1 << 30)))
+        T < (1 << 30) && V < (1 << 30) && H < (1 << 22)))  // (H / 64 is a grid's y extent in the transposition)
     return 0;
   // the kernels count (tile, K split) pairs in 32 bits: at most 2^24 tiles per product (16 splits at most)
   const int64_t tt = (T + kBM - 1) / kBM, th = (H + kBM - 1) / kBM, tv = (V + kBM - 1) / kBM;
@@ -748,7 +750,7 @@ extern "C" int prl_lm_head_bwd_weight(const void* dlogits, int64_t dlogits_strid
               "prl_lm_head_bwd_weight: workspace of %zu bytes needed (prl_lm_head_workspace_bytes), got %zu", need,
               workspace_bytes);
   // hidden^T [H][T] into the workspace, then dweight^T = hidden^T . dlogits stored transposed
-  hipLaunchKernelGGL(k_transpose_bf16, dim3((unsigned)((H + 63) / 64), (unsigned)((T + 63) / 64)), dim3(256), 0,
+  hipLaunchKernelGGL(k_transpose_bf16, dim3((unsigned)((T + 63) / 64), (unsigned)((H + 63) / 64)), dim3(256), 0,
                      (hipStream_t)stream, reinterpret_cast<const uint16_t*>(hidden), hidden_stride,
                      reinterpret_cast<uint16_t*>(workspace), T, (int)T, (int)H);
   PRL_CHECK_LAUNCH("k_transpose_bf16");
