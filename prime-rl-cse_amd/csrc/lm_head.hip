@@ -34,12 +34,14 @@ constexpr int kGemmThreads = 512;
 constexpr int kQuarterBytes = 16384;         // 128 rows x 64 k, or 64 k x 128 columns, of bf16
 constexpr int kStageBytes = 4 * kQuarterBytes;  // P half 0 | P half 1 | Q half 0 | Q half 1
 
-enum { kOutBf16 = 0, kOutF32Slab = 1, kOutBf16Transposed = 2 };
+enum { kOutBf16 = 0, kOutF32Slab = 1, kOutBf16Transposed = 2, kOutF32SlabTransposed = 3 };
+constexpr bool transposed_out(int out) { return out == kOutBf16Transposed || out == kOutF32SlabTransposed; }
 
 struct GemmArgs {
   const uint16_t* P;  // [M][K], ldp elements between rows
   const uint16_t* Q;  // K-major: [N][K]; MN-major: [K][N]; ldq elements between rows
-  void* C;            // bf16 [M][N] (ldc), bf16 [N][M] (ldc, transposed store) or fp32 [nsplit][M][N] (ldc = N)
+  void* C;            // bf16 [M][N] (ldc), bf16 [N][M] (ldc, transposed store), fp32 [nsplit][M][N] (ldc = N) or
+                      // fp32 [nsplit][N][M] (ldc = M, transposed store)
   int64_t ldp, ldq, ldc;
   int64_t slab_stride;  // elements between the fp32 slabs of two K splits
   int M, N;
@@ -306,7 +308,7 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
         for (int c = 0; c < 2; ++c) {
           f32x4& d = acc[4 * h + r][2 * hb + c];
           const bf16x8 q = as_bf16x8(b[c][ks]);
-          d = OUT == kOutBf16Transposed ? mfma16(af[r][ks], q, d) : mfma16(q, af[r][ks], d);
+          d = transposed_out(OUT) ? mfma16(af[r][ks], q, d) : mfma16(q, af[r][ks], d);
         }
     __builtin_amdgcn_s_setprio(0);
   };
@@ -382,6 +384,17 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
             const u32x2_t o = {pack_bf16(x[0], x[1]), pack_bf16(x[2], x[3])};
             *reinterpret_cast<u32x2_t*>(C + (int64_t)n * a.ldc + m) = o;
           }
+        }
+      }
+    } else if (OUT == kOutF32SlabTransposed) {  // a lane's four values are four consecutive m of one n: 16 bytes
+      float* C = reinterpret_cast<float*>(a.C) + (int64_t)split_ * a.slab_stride;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const int n = n0 + wc * 64 + 16 * ct + lr;
+#pragma unroll
+        for (int rt = 0; rt < 8; ++rt) {
+          const int m = m0 + wr * 128 + 16 * rt + 4 * lq;
+          if (inside || (n < a.N && m < a.M)) *reinterpret_cast<f32x4*>(C + (int64_t)n * a.ldc + m) = acc[rt][ct];
         }
       }
     } else {
@@ -627,10 +640,27 @@ static GemmArgs make_args(const void* P, int64_t ldp, const void* Q, int64_t ldq
 // which `gemm_item` deals out in rounds of 256 (`total_items`), and a workgroup without a valid item ends at once.
 static unsigned gemm_grid(const GemmArgs&) { return 256u; }
 
-// K splits for the input-gradient product: few tiles of C, a very long K.  The chip works the (tile, split) pairs off
-// 32 per XCD and round, so a product of `tiles` tiles in s splits takes ceil(ceil(tiles * s / 32) / 8) rounds of
-// ceil(ktiles / s) K-tiles; every split also costs an fp32 slab written and read back (2 % each).  The cheapest
-// count up to 16 that leaves a split at least 8 K-tiles is taken.
+// K splits for a product of `tiles` output tiles over `ktiles` K-tiles whose output is small and whose K is long
+// (the input gradient of the LM head; weight gradients).  The chip works the (tile, split) pairs off 32 per XCD and
+// round, so s splits take ceil(ceil(tiles * s / 32) / 8) rounds of ceil(ktiles / s) K-tiles; every split beyond the
+// first also costs an fp32 slab of the output written and read back, which is priced in K-tile times PER SLAB of 256
+// tiles (`slab_cost`), not relative to the product: a short K does not make a slab cheaper.  Measured: 47.5 for the
+// LM head's input gradient (2 % of its 2374 K-tiles per split), 20 for the weight gradients of a decoder block's
+// layers over a 16 K-token row.  The cheapest count up to 16 that leaves a split at least 8 K-tiles is taken.
+static int k_splits(int64_t tiles, int64_t ktiles, double slab_cost) {
+  double best = 1e30;
+  int best_s = 1;
+  for (int s = 1; s <= 16 && s * 8 <= ktiles; ++s) {
+    const int64_t rounds = ((tiles * s + 31) / 32 + 7) / 8;
+    const double cost = (double)rounds * (double)((ktiles + s - 1) / s) + (s - 1) * slab_cost * (double)tiles / 256.0;
+    if (cost < best * 0.995) {
+      best = cost;
+      best_s = s;
+    }
+  }
+  return best_s;
+}
+
 static int dx_splits(int64_t T, int64_t H, int64_t V) {
   const int64_t tiles = ((T + kBM - 1) / kBM) * ((H + kBN - 1) / kBN);
   const int64_t ktiles = V / kBK;
@@ -638,17 +668,17 @@ static int dx_splits(int64_t T, int64_t H, int64_t V) {
     const int s = atoi(e);
     if (s >= 1 && s <= 16 && (int64_t)s * 2 <= ktiles) return s;
   }
-  double best = 1e30;
-  int best_s = 1;
-  for (int s = 1; s <= 16 && s * 8 <= ktiles; ++s) {
-    const int64_t rounds = ((tiles * s + 31) / 32 + 7) / 8;
-    const double cost = (double)rounds * (double)((ktiles + s - 1) / s) * (1.0 + 0.02 * (s - 1));
-    if (cost < best * 0.995) {
-      best = cost;
-      best_s = s;
-    }
+  return k_splits(tiles, ktiles, 47.5);
+}
+
+static int dw_splits(int64_t T, int64_t H, int64_t V) {
+  const int64_t tiles = ((H + kBM - 1) / kBM) * ((V + kBN - 1) / kBN);
+  const int64_t ktiles = T / kBK;
+  if (const char* e = getenv("PRL_LM_HEAD_DW_SPLITS")) {  // measurements only: a fixed split count
+    const int s = atoi(e);
+    if (s >= 1 && s <= 16 && (int64_t)s * 2 <= ktiles) return s;
   }
-  return best_s;
+  return k_splits(tiles, ktiles, 20.0);
 }
 
 }  // namespace prl
@@ -673,9 +703,11 @@ extern "C" int prl_lm_head_supported(int dtype, int64_t T, int64_t H, int64_t V)
 
 extern "C" size_t prl_lm_head_workspace_bytes(int64_t T, int64_t H, int64_t V) {
   if (T <= 0 || H <= 0 || V <= 0) return 0;
-  const int s = dx_splits(T, H, V);
+  const int s = dx_splits(T, H, V), sw = dw_splits(T, H, V);
   const size_t slabs = s > 1 ? (size_t)s * (size_t)T * (size_t)H * sizeof(float) : 0;
-  const size_t xt = (size_t)T * (size_t)H * sizeof(uint16_t);
+  // the weight gradient: the narrower of hidden and dlogits transposed, and behind it the fp32 slabs of a K split
+  const size_t xt = (size_t)T * (size_t)(V < H ? V : H) * sizeof(uint16_t) +
+                    (sw > 1 ? (size_t)sw * (size_t)V * (size_t)H * sizeof(float) : 0);
   return slabs > xt ? slabs : xt;
 }
 
@@ -745,15 +777,50 @@ extern "C" int prl_lm_head_bwd_weight(const void* dlogits, int64_t dlogits_strid
                   hidden_stride % 8 == 0 && dweight_stride % 4 == 0 && dlogits_stride >= V && hidden_stride >= H &&
                   dweight_stride >= H,
               "prl_lm_head_bwd_weight: pointers must be 16-byte aligned and row strides multiples of 8 elements");
-  const size_t need = (size_t)T * (size_t)H * sizeof(uint16_t);
+  // One operand has to be read along the tokens, so one of the two is transposed into the workspace first: the
+  // narrower one.  hidden^T [H][T]: dweight^T = hidden^T . dlogits, stored transposed (the LM head: V >> H).
+  // dlogits^T [V][T]: dweight = dlogits^T . hidden, stored as it comes (a layer that narrows: V < H).
+  const int s = dw_splits(T, H, V);
+  const bool narrow_out = V < H;
+  const size_t xt_bytes = (size_t)T * (size_t)(narrow_out ? V : H) * sizeof(uint16_t);
+  const size_t need = xt_bytes + (s > 1 ? (size_t)s * (size_t)V * (size_t)H * sizeof(float) : 0);
   PRL_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= need,
               "prl_lm_head_bwd_weight: workspace of %zu bytes needed (prl_lm_head_workspace_bytes), got %zu", need,
               workspace_bytes);
-  // hidden^T [H][T] into the workspace, then dweight^T = hidden^T . dlogits stored transposed
+  PRL_REQUIRE(s == 1 || dweight_stride == H, "prl_lm_head_bwd_weight: a K-split product needs a contiguous dweight");
+  PRL_REQUIRE(!narrow_out || dweight_stride % 8 == 0,
+              "prl_lm_head_bwd_weight: dweight's row stride must be a multiple of 8 elements when V < H");
+  float* slabs = reinterpret_cast<float*>(static_cast<char*>(workspace) + xt_bytes);
+  if (narrow_out) {
+    hipLaunchKernelGGL(k_transpose_bf16, dim3((unsigned)((T + 63) / 64), (unsigned)((V + 63) / 64)), dim3(256), 0,
+                       (hipStream_t)stream, reinterpret_cast<const uint16_t*>(dlogits), dlogits_stride,
+                       reinterpret_cast<uint16_t*>(workspace), T, (int)T, (int)V);
+    PRL_CHECK_LAUNCH("k_transpose_bf16");
+    if (s > 1) {
+      const GemmArgs a = make_args(workspace, T, hidden, hidden_stride, slabs, H, V, H, T, s);
+      hipLaunchKernelGGL((k_lm_gemm<false, kOutF32Slab>), dim3(gemm_grid(a)), dim3(kGemmThreads), 0,
+                         (hipStream_t)stream, a);
+      PRL_CHECK_LAUNCH("k_lm_gemm (weight gradient of a narrowing layer, K split)");
+      return prl_sum_parts(slabs, PRL_F32, V * H, a.nsplit, V * H, dweight, stream);
+    }
+    const GemmArgs a = make_args(workspace, T, hidden, hidden_stride, dweight, dweight_stride, V, H, T, 1);
+    hipLaunchKernelGGL((k_lm_gemm<false, kOutBf16>), dim3(gemm_grid(a)), dim3(kGemmThreads), 0, (hipStream_t)stream,
+                       a);
+    PRL_CHECK_LAUNCH("k_lm_gemm (weight gradient of a narrowing layer)");
+    return PRL_OK;
+  }
   hipLaunchKernelGGL(k_transpose_bf16, dim3((unsigned)((T + 63) / 64), (unsigned)((H + 63) / 64)), dim3(256), 0,
                      (hipStream_t)stream, reinterpret_cast<const uint16_t*>(hidden), hidden_stride,
                      reinterpret_cast<uint16_t*>(workspace), T, (int)T, (int)H);
   PRL_CHECK_LAUNCH("k_transpose_bf16");
+  if (s > 1) {  // a small weight and many tokens: fp32 slabs of dweight [V][H], one per range of the tokens
+    GemmArgs a = make_args(workspace, T, dlogits, dlogits_stride, slabs, V, H, V, T, s);
+    a.ldc = H;  // (the slab is stored transposed: rows of dweight)
+    hipLaunchKernelGGL((k_lm_gemm<false, kOutF32SlabTransposed>), dim3(gemm_grid(a)), dim3(kGemmThreads), 0,
+                       (hipStream_t)stream, a);
+    PRL_CHECK_LAUNCH("k_lm_gemm (weight gradient, K split)");
+    return prl_sum_parts(slabs, PRL_F32, V * H, a.nsplit, V * H, dweight, stream);
+  }
   const GemmArgs a = make_args(workspace, T, dlogits, dlogits_stride, dweight, dweight_stride, H, V, T, 1);
   hipLaunchKernelGGL((k_lm_gemm<false, kOutBf16Transposed>), dim3(gemm_grid(a)), dim3(kGemmThreads), 0,
                      (hipStream_t)stream, a);

@@ -22,6 +22,7 @@ import torch
 from torch import Tensor, nn
 
 from . import _capi as C
+from . import lm_head
 
 
 def _row_layout(x: Tensor):
@@ -326,8 +327,32 @@ def adjacent_rows(*weights: Tensor) -> Tensor | None:
     return torch.as_strided(w0.detach(), (rows, w0.shape[1]), (w0.shape[1], 1))
 
 
+def _on_kernels(rows: int, n_in: int, n_out: int, *operands: Tensor) -> tuple[bool, bool, bool]:
+    """Which of (forward, input gradient, weight gradient) of y = x W^T, x [rows, n_in], W [n_out, n_in], run on the
+    package's MFMA kernels (`lm_head.layer_plan`) rather than the BLAS library."""
+    if any(z.dtype != torch.bfloat16 or not z.is_cuda for z in operands):
+        return (False, False, False)
+    return lm_head.layer_plan(rows, n_in, n_out)
+
+
+def mm_nt(x2: Tensor, w: Tensor) -> Tensor:
+    """x2 [rows, in] . w [out, in]^T."""
+    if _on_kernels(x2.shape[0], w.shape[1], w.shape[0], x2, w)[0]:
+        return lm_head.lm_head_fwd(x2, w)
+    return x2 @ w.t()
+
+
+def mm_nn(gy: Tensor, w: Tensor) -> Tensor:
+    """gy [rows, out] . w [out, in]."""
+    if _on_kernels(gy.shape[0], w.shape[1], w.shape[0], gy, w)[1]:
+        return lm_head.lm_head_bwd_input(gy, w)
+    return gy @ w
+
+
 def weight_grad(gy: Tensor, x: Tensor) -> Tensor:
     """dW = gy^T x for gy [rows, out], x [rows, in] (both contiguous), in gy's dtype.
+
+    On the package's MFMA kernels where `lm_head.layer_plan` says they are ahead; otherwise on the BLAS library:
 
     With a long row (16 K tokens) this product has a small output and a long sum: 1024 x 2048 outputs are 128
     tiles for 256 compute units, and the BLAS library's pick runs at 0.44-0.87 PFLOP/s where the forward products
@@ -339,6 +364,8 @@ def weight_grad(gy: Tensor, x: Tensor) -> Tensor:
     rounding): 8.9 / 7.5 us for fp32 / bf16 parts where torch's reduction (+ conversion) took 14.3 + 4.9 / 14.9."""
     rows, n_out = gy.shape
     n_in = x.shape[1]
+    if _on_kernels(rows, n_in, n_out, gy, x)[2]:
+        return lm_head.lm_head_bwd_weight(gy, x)
     size = n_out * n_in
     s = 4 if size <= 5_000_000 else 2
     if rows < 8192 or rows % s or size > 8_000_000 or gy.dtype != torch.bfloat16:
@@ -361,13 +388,15 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, weight: Tensor):
         ctx.save_for_backward(x, weight)
+        if x.dim() >= 2 and _on_kernels(x.numel() // x.shape[-1], weight.shape[1], weight.shape[0], x, weight)[0]:
+            return lm_head.lm_head_fwd(_rows2d(x), weight).view(*x.shape[:-1], weight.shape[0])
         return torch.nn.functional.linear(x, weight)
 
     @staticmethod
     def backward(ctx, gy: Tensor):
         x, weight = ctx.saved_tensors
         g2 = _rows2d(gy)
-        dx = (g2 @ weight).view(x.shape) if ctx.needs_input_grad[0] else None
+        dx = mm_nn(g2, weight).view(x.shape) if ctx.needs_input_grad[0] else None
         dw = weight_grad(g2, _rows2d(x)) if ctx.needs_input_grad[1] else None
         return dx, dw
 
@@ -392,7 +421,7 @@ class _LinearSplit(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, stacked: Tensor, *weights: Tensor):
         x2 = _rows2d(x)
-        y = x2 @ stacked.t()
+        y = mm_nt(x2, stacked)
         ctx.save_for_backward(x2, stacked)
         ctx.sizes = [w.shape[0] for w in weights]
         ctx.lead = x.shape[:-1]
@@ -405,7 +434,7 @@ class _LinearSplit(torch.autograd.Function):
         parts = [torch.zeros((rows, n), dtype=x2.dtype, device=x2.device) if g is None else g.reshape(rows, n)
                  for g, n in zip(grads, ctx.sizes)]
         gy = torch.cat(parts, dim=1)
-        dx = (gy @ stacked).view(*ctx.lead, x2.shape[1]) if ctx.needs_input_grad[0] else None
+        dx = mm_nn(gy, stacked).view(*ctx.lead, x2.shape[1]) if ctx.needs_input_grad[0] else None
         dw = weight_grad(gy, x2).split(ctx.sizes, dim=0)
         return (dx, None) + tuple(dw)
 
@@ -419,7 +448,7 @@ class _GateUpSwiGLU(torch.autograd.Function):
     def forward(ctx, x: Tensor, stacked: Tensor, wg: Tensor, wu: Tensor):
         dev = x.device
         x2 = _rows2d(x)
-        gu = x2 @ stacked.t()
+        gu = mm_nt(x2, stacked)
         rows, n = x2.shape[0], wg.shape[0]
         out = torch.empty((rows, n), dtype=x.dtype, device=dev)
         es = x.element_size()
@@ -444,7 +473,7 @@ class _GateUpSwiGLU(torch.autograd.Function):
             C.check(C.load().prl_swiglu_rows_bwd(gu.data_ptr(), gu.data_ptr() + n * es, 2 * n, C.ptr(g2), g2.stride(0),
                                                  ggu.data_ptr(), ggu.data_ptr() + n * es, 2 * n, C.dtype_code(gu), rows,
                                                  n, C.stream_ptr(dev)), "prl_swiglu_rows_bwd")
-        dx = (ggu @ stacked).view(*ctx.lead, x2.shape[1]) if ctx.needs_input_grad[0] else None
+        dx = mm_nn(ggu, stacked).view(*ctx.lead, x2.shape[1]) if ctx.needs_input_grad[0] else None
         dw = weight_grad(ggu, x2)
         return dx, None, dw[:n], dw[n:]
 
@@ -640,7 +669,7 @@ class _QKVNormRope(torch.autograd.Function):
         x2 = _rows2d(x)
         t, d = x2.shape[0], 128
         hq, hk = wq.shape[0] // d, wk.shape[0] // d
-        y = x2 @ stacked.t()
+        y = mm_nt(x2, stacked)
         q = torch.empty((t, hq, d), dtype=x.dtype, device=dev)
         k = torch.empty((t, hk, d), dtype=x.dtype, device=dev)
         rstd = torch.empty((t, hq + hk), dtype=torch.float32, device=dev)
@@ -705,7 +734,7 @@ class _QKVNormRope(torch.autograd.Function):
             gy[:, nqk:].copy_(gv.transpose(1, 2).reshape(t, ctx.sizes[2]))
         else:
             gy[:, nqk:].zero_()
-        dx = (gy @ stacked).view(*ctx.lead, x2.shape[1]) if ctx.needs_input_grad[0] else None
+        dx = mm_nn(gy, stacked).view(*ctx.lead, x2.shape[1]) if ctx.needs_input_grad[0] else None
         dw = weight_grad(gy, x2).split(ctx.sizes, dim=0)
         return dx, None, dw[0], dw[1], dw[2], gw[:d], gw[d:], None, None, None
 

@@ -10,6 +10,8 @@ callers that want the library product for such shapes ask `supported()` first.
 
 from __future__ import annotations
 
+import functools
+import math
 import os
 from ctypes import c_int64, c_size_t
 
@@ -115,6 +117,50 @@ def plan(t: int, h: int, v: int) -> tuple[bool, bool, bool]:
     if any(out) and not takes:
         raise RuntimeError(f"the LM-head kernels do not take T={t} H={h} V={v} (multiples of 64 needed)")
     return out[0], out[1], out[2]
+
+
+@functools.lru_cache(maxsize=None)
+def _gemm_table() -> dict[str, dict[int, tuple[float, float, float]]]:
+    """`gemm_table.json` beside this file: for y = x W^T with W [out, in], library time / kernel time of the three
+    products at 4096, 8192 and 16384 rows of x, measured on an MI355X by `tools/body_gemms_ab.py` for the linear
+    layers of the decoder blocks of the recipes' models."""
+    import json
+    from pathlib import Path
+
+    raw = json.loads(Path(__file__).with_name("gemm_table.json").read_text())["ratios"]
+    return {key: {int(t): tuple(r) for t, r in by_t.items()} for key, by_t in raw.items()}
+
+
+LAYER_MARGIN = 1.04  # a product moves to the kernels where they were measured at least this much ahead
+
+
+@functools.lru_cache(maxsize=4096)
+def _layer_plan(mode: str, t: int, n_in: int, n_out: int) -> tuple[bool, bool, bool]:
+    takes = bool(_capi.load().prl_lm_head_supported(_capi.PRL_BF16, t, n_in, n_out))
+    if mode == "hip":
+        return (takes, takes, takes)
+    by_t = _gemm_table().get(f"{n_in}x{n_out}")
+    if not takes or by_t is None:
+        return (False, False, False)
+    nearest = min(by_t, key=lambda m: abs(math.log2(t / m)))
+    if abs(math.log2(t / nearest)) > 0.5:  # (more than a factor 1.41 from anything measured)
+        return (False, False, False)
+    r = by_t[nearest]
+    return (r[0] >= LAYER_MARGIN, r[1] >= LAYER_MARGIN, r[2] >= LAYER_MARGIN)
+
+
+def layer_plan(t: int, n_in: int, n_out: int) -> tuple[bool, bool, bool]:
+    """Which of the three products (forward, input gradient, weight gradient) of a decoder block's linear layer
+    y = x W^T, x [t, n_in], W [n_out, n_in] (bf16), run on this package's kernels: the same three kernels as the LM
+    head's, which is one more such layer.  Default (`PRL_LAYER_GEMMS=auto`): the products that `gemm_table.json` holds
+    as measured at least 4 % ahead of the BLAS library at the nearest measured row count; layers and row counts
+    nobody measured stay with the library.  `lib`: none; `hip`: every product the kernels take."""
+    mode = os.environ.get("PRL_LAYER_GEMMS", "auto")
+    if mode not in ("auto", "hip", "lib"):
+        raise RuntimeError(f"PRL_LAYER_GEMMS must be auto, hip or lib, got {mode!r}")
+    if mode == "lib" or t <= 0:
+        return (False, False, False)
+    return _layer_plan(mode, int(t), int(n_in), int(n_out))
 
 
 class _LMHeadMixed(torch.autograd.Function):

@@ -518,8 +518,9 @@ def test_qk_norm_rope_backward_in_place_on_gradients_that_are_one_matrix(dtype):
         assert torch.equal(g, src)
 
 
-def test_weight_gradient_split_over_the_tokens():
+def test_weight_gradient_split_over_the_tokens(monkeypatch):
     """`weight_grad` at a row long enough to be split, against the float32 product; and the short row left alone."""
+    monkeypatch.setenv("PRL_LAYER_GEMMS", "lib")  # (this is about the products that stay with the BLAS library)
     gen = torch.Generator(device=DEV).manual_seed(12)
     for rows, n_out, n_in in ((16384, 1024, 2048), (16384, 4096, 1024), (8192, 6144, 1024), (2048, 1024, 3072)):
         gy = torch.randn(rows, n_out, generator=gen, device=DEV).to(torch.bfloat16)
@@ -554,3 +555,78 @@ def test_partial_results_added_in_order_and_rounded_once(dtype, nparts, n, strid
     lib = C.load()
     assert lib.prl_sum_parts(C.ptr(parts), C.dtype_code(parts), stride, nparts, 12, C.ptr(out), C.stream_ptr(out.device)) != 0
     assert lib.prl_sum_parts(C.ptr(parts), 7, stride, nparts, n, C.ptr(out), C.stream_ptr(out.device)) != 0
+
+
+def test_block_products_on_the_mfma_kernels(monkeypatch):
+    """The three products of a decoder block's linear layer through `mm_nt`, `mm_nn` and `weight_grad` with the
+    kernels switched on for every shape they take: the LM-head kernels' results (so they did run), and the fp32
+    product of the same bf16 operands to bf16 rounding."""
+    from prime_rl_cse_amd import lm_head as L
+
+    gen = torch.Generator(device=DEV).manual_seed(21)
+    for rows, n_in, n_out in ((4096, 1024, 4096), (4096, 3072, 1024), (8192, 2048, 1024), (2048, 1024, 6144)):
+        x = torch.randn(rows, n_in, generator=gen, device=DEV).to(torch.bfloat16)
+        w = (torch.randn(n_out, n_in, generator=gen, device=DEV) * 0.05).to(torch.bfloat16)
+        gy = (torch.randn(rows, n_out, generator=gen, device=DEV) * 0.1).to(torch.bfloat16)
+        monkeypatch.setenv("PRL_LAYER_GEMMS", "hip")
+        got = fused.mm_nt(x, w), fused.mm_nn(gy, w), fused.weight_grad(gy, x)
+        ours = L.lm_head_fwd(x, w), L.lm_head_bwd_input(gy, w), L.lm_head_bwd_weight(gy, x)
+        want = x.float() @ w.float().t(), gy.float() @ w.float(), gy.float().t() @ x.float()
+        monkeypatch.setenv("PRL_LAYER_GEMMS", "lib")
+        lib = fused.mm_nt(x, w), fused.mm_nn(gy, w), fused.weight_grad(gy, x)
+        for g, o, w32, l, k in zip(got, ours, want, lib, (n_in, n_out, rows)):
+            assert torch.equal(g, o)
+            tol = 2.0 ** -8 * w32.abs() + 1e-6 * k ** 0.5 * w32.abs().max()
+            assert not bool(((g.float() - w32).abs() > tol).any())
+            # and no further from the exact product than the library's result is
+            assert (g.float() - w32).norm().item() <= 1.05 * (l.float() - w32).norm().item() + 1e-6
+
+
+def test_blocks_with_their_products_on_the_kernels_give_the_library_blocks_results(monkeypatch):
+    """Two real-size decoder blocks over a row of 8192 tokens: with the layers' products on the kernels where the
+    measured table puts them, logits and gradients are the library-only run's to bf16 accuracy, and the kernels ran."""
+    import copy
+
+    from prime_rl_cse_amd import attention, lm_head as L
+    from prime_rl_cse_amd import trainer as T
+    from prime_rl_cse_amd.replica import FlatState
+
+    cfg = T.model_config("Qwen/Qwen3-0.6B", num_layers=2, vocab_size=4096)
+    models = [T.get_model(cfg, DEV, torch.bfloat16, seed=5) for _ in range(2)]
+    lengths = [128] * 64
+    t = sum(lengths)
+    gen = torch.Generator().manual_seed(6)
+    ids = torch.randint(0, 4096, (1, t), generator=gen).to(DEV)
+    pos = torch.cat([torch.arange(n) for n in lengths])[None]
+    plan = attention.plan_from_position_ids(pos, DEV)
+    assert any(L.layer_plan(t, 1024, 4096))
+    calls = {"fwd": 0, "dx": 0, "dw": 0}
+    real = L.lm_head_fwd, L.lm_head_bwd_input, L.lm_head_bwd_weight
+
+    def counted(name, fn):
+        def run(*a):
+            calls[name] += 1
+            return fn(*a)
+        return run
+
+    outs = []
+    for model, mode in zip(models, ("auto", "lib")):
+        monkeypatch.setenv("PRL_LAYER_GEMMS", mode)
+        monkeypatch.setenv("PRL_LM_HEAD", "lib")
+        fused.fuse_model(model)
+        state = FlatState(model, compute_dtype=torch.bfloat16)
+        try:
+            L.lm_head_fwd, L.lm_head_bwd_input, L.lm_head_bwd_weight = (counted(n, f) for n, f in zip(calls, real))
+            before = dict(calls)
+            logits = T.forward(model, ids, pos.to(DEV), plan)
+            logits.float().square().mean().backward()
+        finally:
+            L.lm_head_fwd, L.lm_head_bwd_input, L.lm_head_bwd_weight = real
+        ran = {k: calls[k] - before[k] for k in calls}
+        assert (sum(ran.values()) > 0) == (mode == "auto"), ran
+        outs.append((logits.detach().float(), [p.grad.float() for p in state.params]))
+        fused.unfuse_model(model)
+    (la, ga), (lb, gb) = outs
+    assert (la - lb).norm().item() <= 2e-2 * lb.norm().item()
+    for a, b in zip(ga, gb):
+        assert (a - b).norm().item() <= 3e-2 * b.norm().item() + 1e-9

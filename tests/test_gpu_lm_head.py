@@ -21,9 +21,13 @@ def _ints(shape, lo, hi, gen, dev):
 # ragged edges on every side: rows and columns that are not multiples of the 256-wide tile, one K-tile, odd and
 # even numbers of K-tiles, a K split over workgroups with an empty last split (1024 x 256 x 4160), workgroups that
 # walk several tiles with edge tiles among them (1088 x 128 x 16448) and several fp32 slabs of different K splits
-# (5120 x 3840 x 2048)
+# (5120 x 3840 x 2048); many tokens and a small weight, where the WEIGHT gradient is split over ranges of the tokens: a
+# short last split (4160 tokens: 65 K-tiles in 8 splits of 9), ragged tiles in every slab (8192 x 320 x 448), and
+# a decoder block's q + k + v at a joined row's length (16384 x 1024 x 4096); layers that narrow (V < H), whose weight
+# gradient transposes dlogits instead of hidden: split (8192 x 448 x 320, 16384 x 3072 x 1024) and whole (512 x 1088 x 576)
 SHAPES = [(256, 64, 256), (512, 128, 1088), (192, 192, 832), (1024, 256, 4160), (2048, 1024, 2560), (64, 64, 64),
-          (320, 448, 1984), (1088, 128, 16448), (5120, 3840, 2048)]
+          (320, 448, 1984), (1088, 128, 16448), (5120, 3840, 2048), (4160, 256, 1024), (8192, 320, 448),
+          (16384, 1024, 4096), (8192, 448, 320), (16384, 3072, 1024), (512, 1088, 576)]
 
 
 @pytest.mark.parametrize("t,h,v", SHAPES)
