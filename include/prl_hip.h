@@ -519,7 +519,11 @@ int prl_qk_norm_rope_bwd(const void* gq, const int64_t* gq_strides, const void* 
  * over the steps front to back; a product whose K is split over workgroups (dhidden with few rows) adds its fp32
  * partial results in split order, so results are reproducible run to run.
  * workspace: prl_lm_head_workspace_bytes(T, H, V) bytes of device scratch, 16-byte aligned, needed by the two
- * backward products (fp32 partial results of a K split; hidden^T); the forward needs none.
+ * backward products (fp32 partial results of a K split; for the weight gradient also the narrower of hidden and
+ * dlogits transposed); the forward needs none.  A product that is split over K (few output tiles, a long sum)
+ * needs its output contiguous (stride = row length).
+ * The same entry points serve any bias-free linear layer y = x W^T (T rows of x, H = in, V = out): the decoder
+ * blocks' projections run on them where they were measured ahead of the BLAS library.
  */
 int prl_lm_head_supported(int dtype, int64_t T, int64_t H, int64_t V);
 size_t prl_lm_head_workspace_bytes(int64_t T, int64_t H, int64_t V);
