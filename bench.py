@@ -418,6 +418,19 @@ def trainer_measure(dev, world: int, steps: int, warmup: int, cpu: bool, cpu_sec
         "forward_backward_passes_per_step": res.passes,
         "blocks": "transformers Qwen3" + (f", modules on HIP kernels: {fused_modules}" if fused_modules else ""),
     }
+    if fused_modules:
+        # which matrix products of the blocks' linear layers ran on the package's MFMA kernels (the rest: BLAS library)
+        from prime_rl_cse_amd import lm_head
+
+        rows = MICRO_BATCH * SEQ_LEN * len(batches[0]) // max(res.passes, 1)
+        names = ("forward", "input_gradient", "weight_gradient")
+        hq = cfg.num_attention_heads * cfg.head_dim
+        qkv = hq + 2 * cfg.num_key_value_heads * cfg.head_dim
+        out["layer_products_on_mfma_kernels"] = {
+            f"{what} {n_in}->{n_out}": [n for n, on in zip(names, lm_head.layer_plan(rows, n_in, n_out)) if on]
+            for what, n_in, n_out in (("q+k+v", cfg.hidden_size, qkv), ("o", hq, cfg.hidden_size),
+                                      ("gate+up", cfg.hidden_size, 2 * cfg.intermediate_size),
+                                      ("down", cfg.intermediate_size, cfg.hidden_size))}
     if replica is None:
         out["fsdp_blocks_per_group"] = fsdp_groups
     else:
