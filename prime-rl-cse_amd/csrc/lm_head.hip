@@ -20,6 +20,7 @@
 #include <stdlib.h>
 
 #include "prl_common.h"
+#include <cstring>
 
 namespace prl {
 
@@ -124,7 +125,7 @@ constexpr int late_stores() {
   return OUT == kOutBf16 ? 16 : 32;
 }
 
-template <bool Q_KMAJOR, int OUT>
+template <bool P_KMAJOR, bool Q_KMAJOR, int OUT>
 __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[2 * kStageBytes];
 
@@ -160,10 +161,14 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
   const int wr = wid >> 2, wc = wid & 3;
 
   // ---- staging: per thread four 16-byte pieces of P and four of Q per K-tile
-  // P (and a K-major Q): the quarter is [128 rows][64 k] with 128-byte rows; LDS slot (16 bytes) s = row * 8 + chunk
+  // K-major P or Q: the quarter is [128 rows][64 k] with 128-byte rows; LDS slot (16 bytes) s = row * 8 + chunk
   // holds the row's chunk  chunk ^ ((row >> 1) & 7).
   // MN-major Q: the quarter is [64 k][128 columns] with 256-byte rows; slot s = krow * 16 + chunk holds the row's
   // chunk  chunk ^ (f(krow) << 1),  f(krow) = (krow & 3) | (((krow >> 3) & 1) << 2).
+  // MN-major P: the quarter is two pieces of [64 k][64 columns] with 128-byte rows (the first 64 rows of the wave's
+  // part of the tile, which phases 0 and 1 multiply, must be a piece of their own: the loop below waits for the other
+  // piece only before phase 2); slot s = krow * 8 + chunk of a piece holds the row's chunk  chunk ^ (g(krow) << 1),
+  // g(krow) = ((krow >> 3) & 1) | (((krow >> 1) & 1) << 1).
   const uint16_t* psrc[4];
   const uint16_t* qsrc[4];
   int nk = 0;
@@ -172,11 +177,22 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
     nk = a.ktiles - kt0;
     if (nk > a.ktiles_per_split) nk = a.ktiles_per_split;
     const int chunk = (tid & 7) ^ ((tid >> 4) & 7);
+    if (P_KMAJOR) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {  // j = 2 * half + i
-      int row = m0 + 64 * j + (tid >> 3);
-      if (row > a.M - 1) row = a.M - 1;
-      psrc[j] = a.P + (int64_t)row * a.ldp + (int64_t)kt0 * kBK + 8 * chunk;
+      for (int j = 0; j < 4; ++j) {  // j = 2 * half + i
+        int row = m0 + 64 * j + (tid >> 3);
+        if (row > a.M - 1) row = a.M - 1;
+        psrc[j] = a.P + (int64_t)row * a.ldp + (int64_t)kt0 * kBK + 8 * chunk;
+      }
+    } else {
+      const int krow = tid >> 3;
+      const int ch = (tid & 7) ^ ((((krow >> 3) & 1) | (((krow >> 1) & 1) << 1)) << 1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {  // j = 2 * half + i; piece i holds columns 64 i .. 64 i + 63 of the half, 64 k rows
+        int col = m0 + 64 * j + 8 * ch;
+        if (col > a.M - 8) col = a.M - 8;
+        psrc[j] = a.P + ((int64_t)kt0 * kBK + krow) * a.ldp + col;
+      }
     }
     if (Q_KMAJOR) {
 #pragma unroll
@@ -197,7 +213,8 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
       }
     }
   };
-  const int64_t pstep = kBK, qstep = Q_KMAJOR ? (int64_t)kBK : (int64_t)kBK * a.ldq;
+  const int64_t pstep = P_KMAJOR ? (int64_t)kBK : (int64_t)kBK * a.ldp;
+  const int64_t qstep = Q_KMAJOR ? (int64_t)kBK : (int64_t)kBK * a.ldq;
   // LDS destination of piece j of this wave inside a stage (the hardware adds 16 * lane)
   char* const wave_dst = smem + wid * 1024;
 
@@ -227,8 +244,12 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
 
   // ---- fragment addresses (bytes inside a stage)
   // P rows of this wave are the half `wr`; row tile rt adds 2048, k step ks flips bit 6 of the offset
+  // (an MN-major P: row tile rt is the 16-column block rt & 3 of piece rt >> 2, at (p_off ^ (32 (rt & 3))) + 8192 (rt >> 2))
   const int sw = (lane >> 1) & 7;
-  const int p_off = wr * kQuarterBytes + (lane & 15) * 128 + (((lane >> 4)) ^ sw) * 16;
+  const int p_off = P_KMAJOR
+                        ? wr * kQuarterBytes + (lane & 15) * 128 + (((lane >> 4)) ^ sw) * 16
+                        : wr * kQuarterBytes + (8 * (lane >> 4) + ((lane & 15) >> 2)) * 128 +
+                              ((((lane >> 4) & 1) | ((((lane & 15) >> 3) & 1) << 1)) * 32) + 8 * (lane & 3);
   int q_off[4];
   if (Q_KMAJOR) {
     q_off[0] = 2 * kQuarterBytes + (wc >> 1) * kQuarterBytes + ((wc & 1) * 64 + (lane & 15)) * 128 +
@@ -256,14 +277,40 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
 
   f32x4 acc[8][4];
   bf16x8 af[4][2];     // the 64 rows of P this phase multiplies: row tiles 4 h .. 4 h + 3
+  QFrag aq[4][2];      // the same for an MN-major P (transposing reads)
   QFrag bx[2][2];      // Q columns 0 .. 31 of the wave (column tiles 0, 1)
   QFrag by[2][2];      // Q columns 32 .. 63 (column tiles 2, 3)
 
   auto load_a = [&](int stage, int h) {
+    if (P_KMAJOR) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) af[r][ks] = p_frag(stage, 4 * h + r, ks);
+        for (int ks = 0; ks < 2; ++ks) af[r][ks] = p_frag(stage, 4 * h + r, ks);
+    } else {
+      const unsigned base = smem_addr + stage * kStageBytes;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const unsigned ar = base + (unsigned)((p_off ^ (r * 32)) + h * 8192);
+        aq[r][0].lo = lds_read_tr<0>(ar);
+        aq[r][0].hi = lds_read_tr<512>(ar);
+        aq[r][1].lo = lds_read_tr<4096>(ar);
+        aq[r][1].hi = lds_read_tr<4096 + 512>(ar);
+      }
+    }
+  };
+  // an MN-major P: behind the barrier that follows a load_a, before the first use of its fragments (see lds_read_tr)
+  auto wait_a_reads = [&]() {
+    if (!P_KMAJOR) {
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(aq[0][0].lo), "+v"(aq[0][0].hi), "+v"(aq[0][1].lo), "+v"(aq[0][1].hi), "+v"(aq[1][0].lo),
+                     "+v"(aq[1][0].hi), "+v"(aq[1][1].lo), "+v"(aq[1][1].hi), "+v"(aq[2][0].lo), "+v"(aq[2][0].hi),
+                     "+v"(aq[2][1].lo), "+v"(aq[2][1].hi), "+v"(aq[3][0].lo), "+v"(aq[3][0].hi), "+v"(aq[3][1].lo),
+                     "+v"(aq[3][1].hi)
+                   :
+                   : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
   };
   // column tiles 2 hb, 2 hb + 1 of the wave's Q columns into b
   auto load_b = [&](int stage, int hb, QFrag (&b)[2][2]) {
@@ -308,7 +355,8 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
         for (int c = 0; c < 2; ++c) {
           f32x4& d = acc[4 * h + r][2 * hb + c];
           const bf16x8 q = as_bf16x8(b[c][ks]);
-          d = transposed_out(OUT) ? mfma16(af[r][ks], q, d) : mfma16(q, af[r][ks], d);
+          const bf16x8 p = P_KMAJOR ? af[r][ks] : as_bf16x8(aq[r][ks]);
+          d = transposed_out(OUT) ? mfma16(p, q, d) : mfma16(q, p, d);
         }
     __builtin_amdgcn_s_setprio(0);
   };
@@ -458,6 +506,7 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
     load_b((S), 0, bx);                                                             \
     bar();                                                                          \
     PRL_SECTION(1)                                                                  \
+    wait_a_reads();                                                                 \
     wait_tr_reads(bx);                                                              \
     mma(0, 0, bx);                                                                  \
     bar();                                                                          \
@@ -475,6 +524,7 @@ __global__ void __launch_bounds__(kGemmThreads, 2) k_lm_gemm(const GemmArgs a) {
     load_a((S), 1);                                                                 \
     bar();                                                                          \
     PRL_SECTION(5)                                                                  \
+    wait_a_reads();                                                                 \
     mma(1, 1, by);                                                                  \
     bar();                                                                          \
     PRL_SECTION(6)                                                                  \
@@ -671,6 +721,19 @@ static int dx_splits(int64_t T, int64_t H, int64_t V) {
   return k_splits(tiles, ktiles, 47.5);
 }
 
+// The weight gradient's two forms.  Both operands read along the tokens as they lie (transposing LDS reads for
+// both): nothing is copied, but a K-tile takes 4-5 % longer than with a K-major first operand.  Or a transposed
+// copy of the narrower operand in memory first, whose cost goes with T x min(H, V) while the product's goes with
+// T x H x V: measured at 16384 tokens the copy pays from max(H, V) ~ 16384 on (the LM head, a 7B model's gate + up).
+// PRL_LM_HEAD_DW_FORM=both / transpose (measurements only) takes one form everywhere.
+static bool dw_reads_both_along_tokens(int64_t H, int64_t V) {
+  if (const char* e = getenv("PRL_LM_HEAD_DW_FORM")) {
+    if (strcmp(e, "transpose") == 0) return false;
+    if (strcmp(e, "both") == 0) return true;
+  }
+  return (H > V ? H : V) <= 16384;
+}
+
 static int dw_splits(int64_t T, int64_t H, int64_t V) {
   const int64_t tiles = ((H + kBM - 1) / kBM) * ((V + kBN - 1) / kBN);
   const int64_t ktiles = T / kBK;
@@ -726,7 +789,7 @@ extern "C" int prl_lm_head_fwd(const void* hidden, int64_t hidden_stride, const 
   a.stamps = g_stamps;
   a.stamps2 = g_stamps2;
 #endif
-  hipLaunchKernelGGL((k_lm_gemm<true, kOutBf16>), dim3(gemm_grid(a)), dim3(kGemmThreads), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((k_lm_gemm<true, true, kOutBf16>), dim3(gemm_grid(a)), dim3(kGemmThreads), 0, (hipStream_t)stream, a);
   PRL_CHECK_LAUNCH("k_lm_gemm (forward)");
   return PRL_OK;
 }
@@ -748,7 +811,7 @@ extern "C" int prl_lm_head_bwd_input(const void* dlogits, int64_t dlogits_stride
   const int s = dx_splits(T, H, V);
   if (s == 1) {
     const GemmArgs a = make_args(dlogits, dlogits_stride, weight, weight_stride, dhidden, dhidden_stride, T, H, V, 1);
-    hipLaunchKernelGGL((k_lm_gemm<false, kOutBf16>), dim3(gemm_grid(a)), dim3(kGemmThreads), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((k_lm_gemm<true, false, kOutBf16>), dim3(gemm_grid(a)), dim3(kGemmThreads), 0, (hipStream_t)stream,
                        a);
     PRL_CHECK_LAUNCH("k_lm_gemm (input gradient)");
     return PRL_OK;
@@ -759,7 +822,7 @@ extern "C" int prl_lm_head_bwd_input(const void* dlogits, int64_t dlogits_stride
               "prl_lm_head_bwd_input: workspace of %zu bytes needed (prl_lm_head_workspace_bytes), got %zu", need,
               workspace_bytes);
   const GemmArgs a = make_args(dlogits, dlogits_stride, weight, weight_stride, workspace, H, T, H, V, s);
-  hipLaunchKernelGGL((k_lm_gemm<false, kOutF32Slab>), dim3(gemm_grid(a)), dim3(kGemmThreads), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL((k_lm_gemm<true, false, kOutF32Slab>), dim3(gemm_grid(a)), dim3(kGemmThreads), 0, (hipStream_t)stream,
                      a);
   PRL_CHECK_LAUNCH("k_lm_gemm (input gradient, K split)");
   return prl_sum_parts(workspace, PRL_F32, T * H, a.nsplit, T * H, dhidden, stream);
@@ -791,6 +854,22 @@ extern "C" int prl_lm_head_bwd_weight(const void* dlogits, int64_t dlogits_strid
   PRL_REQUIRE(!narrow_out || dweight_stride % 8 == 0,
               "prl_lm_head_bwd_weight: dweight's row stride must be a multiple of 8 elements when V < H");
   float* slabs = reinterpret_cast<float*>(static_cast<char*>(workspace) + xt_bytes);
+  if (dw_reads_both_along_tokens(H, V) && dweight_stride % 8 == 0) {
+    // both operands as they lie, [T][V] and [T][H], read along the tokens by transposing LDS reads: nothing is
+    // transposed in memory, and dweight [V][H] is stored as it comes
+    if (s > 1) {
+      const GemmArgs a = make_args(dlogits, dlogits_stride, hidden, hidden_stride, slabs, H, V, H, T, s);
+      hipLaunchKernelGGL((k_lm_gemm<false, false, kOutF32Slab>), dim3(gemm_grid(a)), dim3(kGemmThreads), 0,
+                         (hipStream_t)stream, a);
+      PRL_CHECK_LAUNCH("k_lm_gemm (weight gradient, K split)");
+      return prl_sum_parts(slabs, PRL_F32, V * H, a.nsplit, V * H, dweight, stream);
+    }
+    const GemmArgs a = make_args(dlogits, dlogits_stride, hidden, hidden_stride, dweight, dweight_stride, V, H, T, 1);
+    hipLaunchKernelGGL((k_lm_gemm<false, false, kOutBf16>), dim3(gemm_grid(a)), dim3(kGemmThreads), 0,
+                       (hipStream_t)stream, a);
+    PRL_CHECK_LAUNCH("k_lm_gemm (weight gradient)");
+    return PRL_OK;
+  }
   if (narrow_out) {
     hipLaunchKernelGGL(k_transpose_bf16, dim3((unsigned)((T + 63) / 64), (unsigned)((V + 63) / 64)), dim3(256), 0,
                        (hipStream_t)stream, reinterpret_cast<const uint16_t*>(dlogits), dlogits_stride,
@@ -798,13 +877,13 @@ extern "C" int prl_lm_head_bwd_weight(const void* dlogits, int64_t dlogits_strid
     PRL_CHECK_LAUNCH("k_transpose_bf16");
     if (s > 1) {
       const GemmArgs a = make_args(workspace, T, hidden, hidden_stride, slabs, H, V, H, T, s);
-      hipLaunchKernelGGL((k_lm_gemm<false, kOutF32Slab>), dim3(gemm_grid(a)), dim3(kGemmThreads), 0,
+      hipLaunchKernelGGL((k_lm_gemm<true, false, kOutF32Slab>), dim3(gemm_grid(a)), dim3(kGemmThreads), 0,
                          (hipStream_t)stream, a);
       PRL_CHECK_LAUNCH("k_lm_gemm (weight gradient of a narrowing layer, K split)");
       return prl_sum_parts(slabs, PRL_F32, V * H, a.nsplit, V * H, dweight, stream);
     }
     const GemmArgs a = make_args(workspace, T, hidden, hidden_stride, dweight, dweight_stride, V, H, T, 1);
-    hipLaunchKernelGGL((k_lm_gemm<false, kOutBf16>), dim3(gemm_grid(a)), dim3(kGemmThreads), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((k_lm_gemm<true, false, kOutBf16>), dim3(gemm_grid(a)), dim3(kGemmThreads), 0, (hipStream_t)stream,
                        a);
     PRL_CHECK_LAUNCH("k_lm_gemm (weight gradient of a narrowing layer)");
     return PRL_OK;
@@ -816,13 +895,13 @@ extern "C" int prl_lm_head_bwd_weight(const void* dlogits, int64_t dlogits_strid
   if (s > 1) {  // a small weight and many tokens: fp32 slabs of dweight [V][H], one per range of the tokens
     GemmArgs a = make_args(workspace, T, dlogits, dlogits_stride, slabs, V, H, V, T, s);
     a.ldc = H;  // (the slab is stored transposed: rows of dweight)
-    hipLaunchKernelGGL((k_lm_gemm<false, kOutF32SlabTransposed>), dim3(gemm_grid(a)), dim3(kGemmThreads), 0,
+    hipLaunchKernelGGL((k_lm_gemm<true, false, kOutF32SlabTransposed>), dim3(gemm_grid(a)), dim3(kGemmThreads), 0,
                        (hipStream_t)stream, a);
     PRL_CHECK_LAUNCH("k_lm_gemm (weight gradient, K split)");
     return prl_sum_parts(slabs, PRL_F32, V * H, a.nsplit, V * H, dweight, stream);
   }
   const GemmArgs a = make_args(workspace, T, dlogits, dlogits_stride, dweight, dweight_stride, H, V, T, 1);
-  hipLaunchKernelGGL((k_lm_gemm<false, kOutBf16Transposed>), dim3(gemm_grid(a)), dim3(kGemmThreads), 0,
+  hipLaunchKernelGGL((k_lm_gemm<true, false, kOutBf16Transposed>), dim3(gemm_grid(a)), dim3(kGemmThreads), 0,
                      (hipStream_t)stream, a);
   PRL_CHECK_LAUNCH("k_lm_gemm (weight gradient)");
   return PRL_OK;

@@ -40,6 +40,21 @@ def test_products_are_exact_on_integer_data(t, h, v):
     assert torch.equal(L.lm_head_bwd_weight(g, x), (g.float().t() @ x.float()).to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("form", ["both", "transpose"])
+@pytest.mark.parametrize("t,h,v", [(1024, 256, 4160), (2048, 1024, 2560), (4160, 256, 1024), (8192, 448, 320),
+                                   (512, 1088, 576), (320, 448, 1984)])
+def test_weight_gradient_is_exact_in_either_form(t, h, v, form, monkeypatch):
+    """The weight gradient reads both operands along the tokens as they lie, or makes a transposed copy of the
+    narrower one first (the library picks by the width of the weight); either form forced here, whole and split over
+    the tokens, ragged tiles, V < H and V > H."""
+    monkeypatch.setenv("PRL_LM_HEAD_DW_FORM", form)
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev).manual_seed(t + h + v)
+    x, g = _ints((t, h), -2, 2, gen, dev), _ints((t, v), -1, 1, gen, dev)
+    for _ in range(3):  # (a stale operand piece would be a matter of timing)
+        assert torch.equal(L.lm_head_bwd_weight(g, x), (g.float().t() @ x.float()).to(torch.bfloat16))
+
+
 def test_products_are_exact_on_random_small_shapes():
     """Thirty shapes drawn from the multiples of 64 (tile counts 1 .. 7 per side, ragged strips of one to three tile
     columns, one to 24 K-tiles, K splits of the input gradient with a short last split)."""

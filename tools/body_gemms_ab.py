@@ -21,6 +21,9 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import prime_rl_cse_amd  # noqa: E402,F401
 from prime_rl_cse_amd import fused, lm_head as L  # noqa: E402
 
+import os  # noqa: E402
+
+os.environ["PRL_LAYER_GEMMS"] = "lib"  # `fused.weight_grad` below is the library's side of the comparison
 T = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 16384
 JSON_OUT = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
 ratios: dict[str, list[float]] = {}

@@ -12,6 +12,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import prime_rl_cse_amd  # noqa: E402,F401
 from prime_rl_cse_amd import fused, lm_head as L  # noqa: E402
 
+os.environ["PRL_LAYER_GEMMS"] = "lib"  # `fused.weight_grad` below is the library's side of the comparison
 t = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 SHAPES = [(1024, 4096), (2048, 1024), (1024, 6144), (3072, 1024), (2048, 4096), (2048, 2048), (2048, 12288), (6144, 2048),
           (3584, 4608), (3584, 3584), (5120, 5120)]
