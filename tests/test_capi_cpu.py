@@ -103,6 +103,13 @@ def test_lm_head_host_logic_needs_no_device():
     ws = lib.prl_lm_head_workspace_bytes(2048, 1024, 151936)
     assert ws % (2048 * 1024 * 4) == 0 and 2 <= ws // (2048 * 1024 * 4) <= 16
     assert lib.prl_lm_head_workspace_bytes(0, 1024, 151936) == 0
+    # A decoder block's layers (the same entry points): a K split is priced per fp32 slab of the output, not relative
+    # to the product, so a short K stays whole (8192 x 3584 x 4608: 72 K-tiles, nothing but the transposed copy of the
+    # narrower operand), and a small weight under many tokens splits its WEIGHT gradient over the tokens (4 slabs of
+    # 4096 x 1024 for q + k + v at 16384 rows, 8 of 1024 x 2048 for o; the copy is of the narrower operand)
+    assert lib.prl_lm_head_workspace_bytes(8192, 3584, 4608) == 8192 * 3584 * 2
+    assert lib.prl_lm_head_workspace_bytes(16384, 1024, 4096) == 16384 * 1024 * 2 + 4 * 4096 * 1024 * 4
+    assert lib.prl_lm_head_workspace_bytes(16384, 2048, 1024) == 16384 * 1024 * 2 + 8 * 1024 * 2048 * 4
     # refusals come before any launch
     assert lib.prl_lm_head_fwd(null, 1024, one, 1024, one, 151936, 2048, 1024, 151936, null) == -1
     assert b"null" in lib.prl_last_error()
