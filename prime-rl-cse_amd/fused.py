@@ -383,14 +383,18 @@ def weight_grad(gy: Tensor, x: Tensor) -> Tensor:
 
 
 class _Linear(torch.autograd.Function):
-    """x W^T without a bias, as nn.Linear computes it; the backward's dW goes through `weight_grad`."""
+    """x W^T (+ bias), as nn.Linear computes it, with each of the three products on the side `lm_head.layer_plan`
+    names; the library's weight gradient goes through `weight_grad`.  With a bias the forward stays the library's
+    (which adds the bias inside its product) and the bias's gradient is the column sum autograd would form."""
 
     @staticmethod
-    def forward(ctx, x: Tensor, weight: Tensor):
+    def forward(ctx, x: Tensor, weight: Tensor, bias: Tensor | None = None):
         ctx.save_for_backward(x, weight)
-        if x.dim() >= 2 and _on_kernels(x.numel() // x.shape[-1], weight.shape[1], weight.shape[0], x, weight)[0]:
+        ctx.has_bias = bias is not None
+        if bias is None and x.dim() >= 2 \
+                and _on_kernels(x.numel() // x.shape[-1], weight.shape[1], weight.shape[0], x, weight)[0]:
             return lm_head.lm_head_fwd(_rows2d(x), weight).view(*x.shape[:-1], weight.shape[0])
-        return torch.nn.functional.linear(x, weight)
+        return torch.nn.functional.linear(x, weight, bias)
 
     @staticmethod
     def backward(ctx, gy: Tensor):
@@ -398,15 +402,16 @@ class _Linear(torch.autograd.Function):
         g2 = _rows2d(gy)
         dx = mm_nn(g2, weight).view(x.shape) if ctx.needs_input_grad[0] else None
         dw = weight_grad(g2, _rows2d(x)) if ctx.needs_input_grad[1] else None
-        return dx, dw
+        db = g2.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db
 
 
 def _split_dw_linear_forward(self: nn.Module, x: Tensor) -> Tensor:
-    w = self.weight
-    if self.bias is not None or hasattr(w, "to_local") or not x.is_cuda or x.dtype != w.dtype \
+    w, b = self.weight, self.bias
+    if hasattr(w, "to_local") or not x.is_cuda or x.dtype != w.dtype or (b is not None and b.dtype != w.dtype) \
             or not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)):
         return self._prl_torch_forward(x)
-    return _Linear.apply(x, w)
+    return _Linear.apply(x, w, b)
 
 
 def _rows2d(x: Tensor) -> Tensor:
@@ -867,9 +872,16 @@ def fuse_model(model: nn.Module) -> dict[str, int]:
             module._prl_torch_forward = module.forward
             module.forward = types.MethodType(_fused_mlp_forward, module)
             done["swiglu"] += 1
-        for attr in ("o_proj", "down_proj"):  # the blocks' other two products: only their weight gradient changes
+        # The blocks' other linear layers, one by one: o and down always; gate and up for the passes in which they are
+        # not one stacked product (`_fused_mlp_forward` calls the modules then); q, k and v where they carry a bias
+        # (no stacked product for those).  Each product goes where `lm_head.layer_plan` has it measured.
+        one_by_one = ["o_proj", "down_proj"] + (["gate_proj", "up_proj"] if is_gated_mlp else [])
+        if name.endswith("Attention") and any(getattr(getattr(module, a, None), "bias", None) is not None
+                                              for a in ("q_proj", "k_proj", "v_proj")):
+            one_by_one += ["q_proj", "k_proj", "v_proj"]
+        for attr in one_by_one:
             lin = getattr(module, attr, None)
-            if isinstance(lin, nn.Linear) and lin.bias is None and not hasattr(lin, "_prl_torch_forward") \
+            if isinstance(lin, nn.Linear) and not hasattr(lin, "_prl_torch_forward") \
                     and (name.endswith("Attention") or name.endswith("MLP")):
                 lin._prl_torch_forward = lin.forward
                 lin.forward = types.MethodType(_split_dw_linear_forward, lin)

@@ -131,7 +131,10 @@ def _gemm_table() -> dict[str, dict[int, tuple[float, float, float]]]:
     return {key: {int(t): tuple(r) for t, r in by_t.items()} for key, by_t in raw.items()}
 
 
-LAYER_MARGIN = 1.04  # a product moves to the kernels where they were measured at least this much ahead
+# A product moves to the kernels where they were measured at least this much ahead: (forward, input gradient, weight
+# gradient).  The forward's bar is higher: there kernels and library are close for most layers, and the library's
+# time for one and the same shape moves by up to 10 % from one measurement to the next.
+LAYER_MARGINS = (1.10, 1.04, 1.04)
 
 
 @functools.lru_cache(maxsize=4096)
@@ -146,15 +149,15 @@ def _layer_plan(mode: str, t: int, n_in: int, n_out: int) -> tuple[bool, bool, b
     if abs(math.log2(t / nearest)) > 0.5:  # (more than a factor 1.41 from anything measured)
         return (False, False, False)
     r = by_t[nearest]
-    return (r[0] >= LAYER_MARGIN, r[1] >= LAYER_MARGIN, r[2] >= LAYER_MARGIN)
+    return (r[0] >= LAYER_MARGINS[0], r[1] >= LAYER_MARGINS[1], r[2] >= LAYER_MARGINS[2])
 
 
 def layer_plan(t: int, n_in: int, n_out: int) -> tuple[bool, bool, bool]:
     """Which of the three products (forward, input gradient, weight gradient) of a decoder block's linear layer
     y = x W^T, x [t, n_in], W [n_out, n_in] (bf16), run on this package's kernels: the same three kernels as the LM
     head's, which is one more such layer.  Default (`PRL_LAYER_GEMMS=auto`): the products that `gemm_table.json` holds
-    as measured at least 4 % ahead of the BLAS library at the nearest measured row count; layers and row counts
-    nobody measured stay with the library.  `lib`: none; `hip`: every product the kernels take."""
+    as measured at least 4 % (the forward: 10 %) ahead of the BLAS library at the nearest measured row count; layers
+    and row counts nobody measured stay with the library.  `lib`: none; `hip`: every product the kernels take."""
     mode = os.environ.get("PRL_LAYER_GEMMS", "auto")
     if mode not in ("auto", "hip", "lib"):
         raise RuntimeError(f"PRL_LAYER_GEMMS must be auto, hip or lib, got {mode!r}")

@@ -160,7 +160,7 @@ def test_loss_config_defaults_match_reference():
 
 
 def test_layer_plan_follows_the_measured_table(monkeypatch):
-    """Which products of a decoder block's layers go to the MFMA kernels: those measured at least `LAYER_MARGIN` ahead
+    """Which products of a decoder block's layers go to the MFMA kernels: those measured at least `LAYER_MARGINS` ahead
     at the nearest measured row count; nothing for layers or row counts nobody measured, or shapes the kernels do
     not take; PRL_LAYER_GEMMS overrides."""
     from prime_rl_cse_amd import lm_head as L
@@ -172,18 +172,18 @@ def test_layer_plan_follows_the_measured_table(monkeypatch):
         n_in, n_out = (int(z) for z in key.split("x"))
         assert set(by_t) == {4096, 8192, 16384}
         for t, ratios in by_t.items():
-            assert L.layer_plan(t, n_in, n_out) == tuple(r >= L.LAYER_MARGIN for r in ratios)
+            assert L.layer_plan(t, n_in, n_out) == tuple(r >= m for r, m in zip(ratios, L.LAYER_MARGINS))
         assert L.layer_plan(14000 // 64 * 64, n_in, n_out) == L.layer_plan(16384, n_in, n_out)
         assert L.layer_plan(6400, n_in, n_out) == L.layer_plan(8192, n_in, n_out)
         assert L.layer_plan(2048, n_in, n_out) == (False, False, False)  # too far from anything measured
         assert L.layer_plan(65536, n_in, n_out) == (False, False, False)
         assert L.layer_plan(16384 + 8, n_in, n_out) == (False, False, False)  # not a multiple of 64
-    assert L.layer_plan(16384, 1024, 1024) == (False, False, False)  # not in the table
+    assert L.layer_plan(16384, 1024, 1536) == (False, False, False)  # not in the table
     monkeypatch.setenv("PRL_LAYER_GEMMS", "lib")
     assert L.layer_plan(16384, 3584, 37888) == (False, False, False)
     monkeypatch.setenv("PRL_LAYER_GEMMS", "hip")
-    assert L.layer_plan(16384, 1024, 1024) == (True, True, True)
-    assert L.layer_plan(100, 1024, 1024) == (False, False, False)
+    assert L.layer_plan(16384, 1024, 1536) == (True, True, True)
+    assert L.layer_plan(100, 1024, 1536) == (False, False, False)
     monkeypatch.setenv("PRL_LAYER_GEMMS", "fast")
     with pytest.raises(RuntimeError, match="PRL_LAYER_GEMMS"):
-        L.layer_plan(16384, 1024, 1024)
+        L.layer_plan(16384, 1024, 1536)

@@ -325,7 +325,7 @@ def test_fuse_model_rebinds_the_gated_mlps():
     cfg = T.model_config("Qwen/Qwen3-0.6B", num_layers=3)
     model = T.get_model(cfg, DEV, torch.bfloat16, seed=3)
     done = fused.fuse_model(model)
-    assert done == {"rmsnorm": 13, "rope": 1, "swiglu": 3, "qkv": 3, "linear": 6, "layer": 3, "lm_head": 1}
+    assert done == {"rmsnorm": 13, "rope": 1, "swiglu": 3, "qkv": 3, "linear": 12, "layer": 3, "lm_head": 1}
     ids = torch.randint(0, 1000, (1, 64), device=DEV)
     pos = torch.arange(64, device=DEV)[None]
     timer = prl._capi.KernelTimer()
@@ -630,3 +630,25 @@ def test_blocks_with_their_products_on_the_kernels_give_the_library_blocks_resul
     assert (la - lb).norm().item() <= 2e-2 * lb.norm().item()
     for a, b in zip(ga, gb):
         assert (a - b).norm().item() <= 3e-2 * b.norm().item() + 1e-9
+
+
+def test_linear_with_a_bias_keeps_its_forward_and_moves_its_gradients(monkeypatch):
+    """A layer with a bias (Qwen2.5's q, k, v): the forward stays `F.linear` with the bias, bit for bit; the input and
+    weight gradients come from the kernels (every product switched to them here) and the bias's gradient is the
+    column sum, all to bf16 accuracy of what autograd gives for `nn.Linear`."""
+    gen = torch.Generator(device=DEV).manual_seed(31)
+    lin = torch.nn.Linear(1024, 512, bias=True, device=DEV, dtype=torch.bfloat16)
+    x = torch.randn(1, 4096, 1024, generator=gen, device=DEV).to(torch.bfloat16).requires_grad_()
+    gy = (torch.randn(1, 4096, 512, generator=gen, device=DEV) * 0.1).to(torch.bfloat16)
+    want = lin(x)
+    want.backward(gy)
+    ref = x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()
+    x.grad = lin.weight.grad = lin.bias.grad = None
+    monkeypatch.setenv("PRL_LAYER_GEMMS", "hip")
+    lin._prl_torch_forward = lin.forward
+    got = fused._split_dw_linear_forward(lin, x)
+    assert got.grad_fn is not None and "Linear" in type(got.grad_fn).__name__ and torch.equal(got, want)
+    got.backward(gy)
+    for g, r in zip((x.grad, lin.weight.grad, lin.bias.grad), ref):
+        assert g.shape == r.shape and g.dtype == r.dtype
+        assert (g.float() - r.float()).norm().item() <= 1e-2 * r.float().norm().item()
