@@ -948,8 +948,37 @@ class Replica:
                           seconds=seconds, tokens=state["tokens"], samples=samples, passes=state["passes"])
 
 
-def eligible(model: nn.Module, optim_type: str, activation_checkpointing: bool = False) -> str | None:
-    """None when `Replica` can train this model, otherwise the reason it cannot (then FSDP2 does)."""
+def whole_model_bytes(model: nn.Module, tokens_per_pass: int, world: int = 1) -> int:
+    """What one rank of `Replica` holds at the peak of a step WITHOUT activation checkpointing, in bytes, for a
+    forward / backward pass over `tokens_per_pass` tokens: the bf16 model and the fp32 gradient sums whole, fp32
+    master weights and the two AdamW moments as a 1 / world shard, every block's saved activations, and the logits
+    with their gradient.  The activations of a block are counted as the bf16 tensors its autograd functions keep:
+    6 hidden-wide ones (inputs of the two norms, their outputs, the attention output, the residual), the q / k / v
+    product and the rotated queries and keys, the gate / up product and the activation's output.  Checked against
+    the allocator's peak for Qwen2.5-7B at 16384 tokens on one rank: 205 GiB measured, 215 GiB by this count."""
+    cfg = model.config
+    n = sum(p.numel() for p in model.parameters())
+    h, inter = int(cfg.hidden_size), int(cfg.intermediate_size)
+    head = int(getattr(cfg, "head_dim", None) or h // cfg.num_attention_heads)
+    q_wide, kv_wide = head * int(cfg.num_attention_heads), head * int(cfg.num_key_value_heads)
+    per_token_and_block = 2 * (6 * h + 2 * (q_wide + 2 * kv_wide) + q_wide + 3 * inter)
+    state = 2 * n + 4 * n + (12 * n + world - 1) // world
+    activations = tokens_per_pass * int(cfg.num_hidden_layers) * per_token_and_block
+    logits = tokens_per_pass * int(cfg.vocab_size) * (2 + 2) + tokens_per_pass * h * 8
+    return state + activations + logits
+
+
+HBM_SHARE = 0.85  # of a GPU's memory that a whole-model step may be estimated at (the rest: workspaces, fragmentation)
+
+
+def eligible(model: nn.Module, optim_type: str, activation_checkpointing: bool = False,
+             tokens_per_pass: int = 16384, world: int = 1, hbm_bytes: int | None = None) -> str | None:
+    """None when `Replica` can train this model, otherwise the reason it cannot (then FSDP2 does).
+
+    Activation checkpointing, as the reference's recipes for 80 GB GPUs ask for it (`model.ac`), trades a second
+    forward pass for memory and changes no result.  `Replica` does not re-run blocks inside backward, so a model
+    that asks for it is taken only if a step WITHOUT checkpointing fits the GPU (`whole_model_bytes` against
+    `HBM_SHARE` of `hbm_bytes`, default: the 288 GB of an MI355X): then the recipe's request is simply not needed."""
     from .trainer import keeps_parameters_gathered
 
     if not keeps_parameters_gathered(model):
@@ -957,5 +986,9 @@ def eligible(model: nn.Module, optim_type: str, activation_checkpointing: bool =
     if optim_type not in ("adamw", "sgd"):
         return f"optimizer {optim_type!r} is not element-wise over a flat shard"
     if activation_checkpointing:
-        return "activation checkpointing re-runs blocks inside backward"
+        hbm = 288 * 10**9 if hbm_bytes is None else int(hbm_bytes)
+        need = whole_model_bytes(model, tokens_per_pass, world)
+        if need > HBM_SHARE * hbm:
+            return (f"activation checkpointing is needed (a step without it is estimated at {need / 2**30:.0f} GiB of "
+                    f"{hbm / 2**30:.0f}), and it re-runs blocks inside backward")
     return None

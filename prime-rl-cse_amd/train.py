@@ -186,7 +186,14 @@ def _train(config: RLTrainerConfig, world: Any, device: torch.device, mesh: Any)
     if mode != "fsdp":
         from .replica import Replica, eligible
 
-        reason = eligible(T.get_model(model_config_of(config), "meta"), config.optim.type, config.model.ac is not None)
+        # a pass is as long as the joined rows of a step get (trainer.MERGE_MAX_TOKENS), or one micro-batch if longer
+        fake = config.data.fake
+        tokens = max(T.MERGE_MAX_TOKENS, fake.micro_batch_size * fake.seq_len if fake else 0)
+        reason = eligible(T.get_model(model_config_of(config), "meta"), config.optim.type, config.model.ac is not None,
+                          tokens_per_pass=tokens, world=world.world_size,
+                          hbm_bytes=torch.cuda.get_device_properties(device).total_memory)
+        if reason is None and config.model.ac is not None:
+            log("activation checkpointing was asked for and is not needed: a step without it fits this GPU")
         if reason is None:
             model, model_cfg = build_model(config, device, mesh, shard=False)
             graphs = replay_graphs(config)

@@ -369,7 +369,13 @@ def test_eligibility():
     model = T.get_model(tiny_config(), "meta", torch.float32)
     assert eligible(model, "adamw") is None and eligible(model, "sgd") is None
     assert "element-wise" in eligible(model, "muon")
-    assert "checkpointing" in eligible(model, "adamw", activation_checkpointing=True)
+    # activation checkpointing is a reason only where a step without it would not fit the GPU
+    assert eligible(model, "adamw", activation_checkpointing=True) is None
+    assert "checkpointing" in eligible(model, "adamw", activation_checkpointing=True, hbm_bytes=10**6)
+    big = T.get_model(T.model_config("willcb/DeepSeek-R1-Distill-Qwen-7B"), "meta", torch.bfloat16)
+    assert eligible(big, "adamw", activation_checkpointing=True, tokens_per_pass=16384) is None  # 215 of 268 GiB
+    assert "checkpointing" in eligible(big, "adamw", activation_checkpointing=True, hbm_bytes=80 * 10**9)
+    assert "checkpointing" in eligible(big, "adamw", activation_checkpointing=True, tokens_per_pass=32768)
 
 
 def _param_steps(before, model):
