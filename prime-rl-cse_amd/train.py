@@ -186,9 +186,10 @@ def _train(config: RLTrainerConfig, world: Any, device: torch.device, mesh: Any)
     if mode != "fsdp":
         from .replica import Replica, eligible
 
-        # a pass is as long as the joined rows of a step get (trainer.MERGE_MAX_TOKENS), or one micro-batch if longer
+        # a pass is as long as the joined rows of a step get (trainer.MERGE_MAX_TOKENS), or one micro-batch if longer;
+        # rollout files say nothing about their rows' length ahead of time: twice the joined length is assumed
         fake = config.data.fake
-        tokens = max(T.MERGE_MAX_TOKENS, fake.micro_batch_size * fake.seq_len if fake else 0)
+        tokens = max(T.MERGE_MAX_TOKENS, fake.micro_batch_size * fake.seq_len) if fake else 2 * T.MERGE_MAX_TOKENS
         reason = eligible(T.get_model(model_config_of(config), "meta"), config.optim.type, config.model.ac is not None,
                           tokens_per_pass=tokens, world=world.world_size,
                           hbm_bytes=torch.cuda.get_device_properties(device).total_memory)
