@@ -51,7 +51,8 @@ RECIPES = {
     "reverse_text": ("reverse_text_fake.toml", "Qwen3-0.6B reverse_text GRPO, rows of 16 x 128 tokens"),
     "wordle": ("wordle_1p7b_fake.toml", "Qwen3-1.7B wordle GRPO, rows of 1 x 4096 tokens, 32 rollouts per rank and step"),
     "hendrycks_7b": ("hendrycks_7b_fake.toml", "Qwen2.5-7B hendrycks_math GRPO, rows of 2 x 2048 tokens, activation "
-                                               "checkpointing, 32 rollouts per rank and step"),
+                                               "checkpointing asked for (the trainer drops it where a step without "
+                                               "it fits the GPU), 32 rollouts per rank and step"),
     "hendrycks_32b_8_layers": ("hendrycks_32b_8_layers_fake.toml",
                                "Qwen2.5-32B hendrycks_math GRPO cut to 8 of its 64 blocks (what one GPU holds), rows of "
                                "8 x 2048 tokens, activation checkpointing, 32 rollouts per rank and step"),
