@@ -972,13 +972,15 @@ HBM_SHARE = 0.85  # of a GPU's memory that a whole-model step may be estimated a
 
 
 def eligible(model: nn.Module, optim_type: str, activation_checkpointing: bool = False,
-             tokens_per_pass: int = 16384, world: int = 1, hbm_bytes: int | None = None) -> str | None:
+             tokens_per_pass: int = 16384, world: int = 1, hbm_bytes: int | None = None,
+             extra_bytes: int = 0) -> str | None:
     """None when `Replica` can train this model, otherwise the reason it cannot (then FSDP2 does).
 
     Activation checkpointing, as the reference's recipes for 80 GB GPUs ask for it (`model.ac`), trades a second
     forward pass for memory and changes no result.  `Replica` does not re-run blocks inside backward, so a model
     that asks for it is taken only if a step WITHOUT checkpointing fits the GPU (`whole_model_bytes` against
-    `HBM_SHARE` of `hbm_bytes`, default: the 288 GB of an MI355X): then the recipe's request is simply not needed."""
+    `HBM_SHARE` of `hbm_bytes`, default: the 288 GB of an MI355X): then the recipe's request is simply not needed.
+    `extra_bytes`: what else the caller keeps on the GPU (a second copy of the model for recomputed log-probabilities)."""
     from .trainer import keeps_parameters_gathered
 
     if not keeps_parameters_gathered(model):
@@ -987,7 +989,7 @@ def eligible(model: nn.Module, optim_type: str, activation_checkpointing: bool =
         return f"optimizer {optim_type!r} is not element-wise over a flat shard"
     if activation_checkpointing:
         hbm = 288 * 10**9 if hbm_bytes is None else int(hbm_bytes)
-        need = whole_model_bytes(model, tokens_per_pass, world)
+        need = whole_model_bytes(model, tokens_per_pass, world) + int(extra_bytes)
         if need > HBM_SHARE * hbm:
             return (f"activation checkpointing is needed (a step without it is estimated at {need / 2**30:.0f} GiB of "
                     f"{hbm / 2**30:.0f}), and it re-runs blocks inside backward")

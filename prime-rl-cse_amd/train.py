@@ -190,9 +190,11 @@ def _train(config: RLTrainerConfig, world: Any, device: torch.device, mesh: Any)
         # rollout files say nothing about their rows' length ahead of time: twice the joined length is assumed
         fake = config.data.fake
         tokens = max(T.MERGE_MAX_TOKENS, fake.micro_batch_size * fake.seq_len) if fake else 2 * T.MERGE_MAX_TOKENS
-        reason = eligible(T.get_model(model_config_of(config), "meta"), config.optim.type, config.model.ac is not None,
-                          tokens_per_pass=tokens, world=world.world_size,
-                          hbm_bytes=torch.cuda.get_device_properties(device).total_memory)
+        meta = T.get_model(model_config_of(config), "meta")
+        second_model = 2 * sum(p.numel() for p in meta.parameters()) if config.recompute_logprobs else 0
+        reason = eligible(meta, config.optim.type, config.model.ac is not None, tokens_per_pass=tokens,
+                          world=world.world_size, hbm_bytes=torch.cuda.get_device_properties(device).total_memory,
+                          extra_bytes=second_model)
         if reason is None and config.model.ac is not None:
             log("activation checkpointing was asked for and is not needed: a step without it fits this GPU")
         if reason is None:
